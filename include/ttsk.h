@@ -1,0 +1,183 @@
+/*
+ * ttsk.h -- C ABI of libttsk.so: the MI355X (gfx950) implementation of the
+ * streaming TT-sketch hot path of RikVoorhaar/tt-sketch.
+ *
+ * The reference has exactly one native module (tt_sketch/drm/fast_lazy_gaussian.pyx);
+ * everything else on the path is Python plug-in surface (DRM.sketch_* generators and
+ * the sketch_omega_* / sketch_psi_* tables).  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative ttsk_status; the message of
+ *    the last failure on the calling thread is ttsk_last_error().  No exceptions
+ *    cross the boundary.
+ *  - "dev" pointers are device addresses obtained from ttsk_malloc; "host" pointers
+ *    are ordinary process memory.  The library never keeps or frees host pointers.
+ *  - all floating point data is fp64; index data is int64 (as the reference stores
+ *    it) unless stated; hashes are uint64.
+ *  - calls are asynchronous on the library's stream `stream` (0..TTSK_NUM_STREAMS-1)
+ *    unless they take host pointers, in which case they block until the data is valid.
+ */
+#ifndef TTSK_H
+#define TTSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TTSK_OK = 0,
+    TTSK_ERR_HIP = -1,      /* a HIP runtime call failed (no device, OOM, launch failure) */
+    TTSK_ERR_ARG = -2,      /* invalid argument (shape / stride / NULL) -> Python ValueError */
+    TTSK_ERR_UNSUPPORTED = -3,
+    TTSK_ERR_COMM = -4      /* RCCL failure */
+} ttsk_status;
+
+#define TTSK_NUM_STREAMS 4
+
+/* ---- runtime ------------------------------------------------------------ */
+int ttsk_init(int device);                    /* selects the device, creates streams; idempotent */
+int ttsk_shutdown(void);
+const char *ttsk_last_error(void);
+int ttsk_device_info(char *name, size_t name_len, int *num_cu, size_t *hbm_bytes);
+int ttsk_malloc(void **dev, size_t bytes);
+int ttsk_free(void *dev);
+int ttsk_memset(void *dev, int value, size_t bytes, int stream);
+int ttsk_h2d(void *dev, const void *host, size_t bytes, int stream);   /* blocking */
+int ttsk_d2h(void *host, const void *dev, size_t bytes, int stream);   /* blocking */
+int ttsk_d2d(void *dst, const void *src, size_t bytes, int stream);
+int ttsk_sync(int stream);                    /* stream < 0: all streams */
+int ttsk_stream_wait(int waiter, int signaller); /* waiter waits for work queued so far on signaller */
+/* hipEvent timing on a library stream (bench.py roofline leg) */
+int ttsk_timer_start(int stream);
+int ttsk_timer_stop(int stream, float *ms);   /* blocks until the stop event completes */
+/* hipGraph capture of a launch sequence on one stream (launch-bound inner loops) */
+int ttsk_graph_begin(int stream);
+int ttsk_graph_end(int stream, void **graph_exec);
+int ttsk_graph_launch(void *graph_exec, int stream);
+int ttsk_graph_free(void *graph_exec);
+
+/* ---- generic fp64 contraction (MFMA 16x16x4) -----------------------------
+ * C[b,m,n] (+)= alpha * sum_{ko,ki} A[b,m,ko,ki] * B[b,ko,ki,n]
+ * with arbitrary element strides.  This is the device counterpart of the
+ * np.einsum / tensordot / `@` calls in tt_sketch/drm/tensor_train_drm.py:79-141,
+ * tt_sketch/drm/dense_gaussian_drm.py:72-75, tt_sketch/tensor.py:390-397 and
+ * tt_sketch/sketching_methods/{tensor_train,cp,dense,tucker}_sketch.py.
+ * Optional row scaling of A by a vector (sparse_sketch.py:46, `left * entries`). */
+typedef struct {
+    int64_t batch, M, N, Ko, Ki;
+    int64_t a_b, a_m, a_ko, a_ki;    /* element strides of A */
+    int64_t b_b, b_ko, b_ki, b_n;    /* element strides of B */
+    int64_t c_b, c_m, c_n;           /* element strides of C */
+    double alpha;
+    int accumulate;                  /* 0: C = ..., 1: C += ... */
+    int split_k;                     /* 0: library chooses; >=1 explicit */
+} ttsk_gemm_desc;
+int ttsk_gemm(const ttsk_gemm_desc *desc, const double *A, const double *B, double *C,
+              const double *k_scale /* NULL or length Ko*Ki, multiplies A along k */,
+              int stream);
+/* strided copy / permute (<= 5 dims): dst[i0..i4] = src[i0..i4]; Tensor.T materialisation */
+int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *shape,
+                      const int64_t *dst_strides, const int64_t *src_strides, int stream);
+/* y[i] = a*x[i] + b*y[i] on contiguous buffers: SketchContainer.__add__
+ * (sketch_container.py:61-69) and the TensorSum accumulators (sketch_dispatch.py:93-136) */
+int ttsk_axpby(double *y, const double *x, double a, double b, size_t n, int stream);
+
+/* ---- fused TT-input / TT-DRM kernels --------------------------------------
+ * One chain step of TensorTrainDRM.sketch_tt (tensor_train_drm.py:71-88) fused
+ * with the interior Psi contraction that shares its first GEMM
+ * (tensor_train_sketch.py:28-34):
+ *   T[q,k,p']  = sum_p  Lin[p,q] * X[p,k,p']
+ *   Lout[p',q'] = sum_{q,k} T[q,k,p'] * D[q,k,q']          (if Lout != NULL)
+ *   Psi[q,k,c] = sum_{p'} T[q,k,p'] * R[p',c]             (if Psi != NULL)
+ * X is addressed through element strides (x_p, x_k, x_pp) so that the transposed
+ * tensor of a right sketch (tensor.py:311-313) needs no copy.  Lin may be NULL for
+ * the first mode (s = l = 1, T = X).  Lout accumulates atomically and must be
+ * zeroed by the caller (ttsk_memset).  Columns [q_lo, q_hi) of the running
+ * contraction are the DRM's rank_min/rank_max slice and are applied by the caller
+ * through pointer/ld arithmetic (tensor_train_drm.py:88). */
+typedef struct {
+    int64_t s, n, sp;      /* X is (s, n, sp) through strides */
+    int64_t l, lp;         /* DRM core D is (l, n, lp), contiguous */
+    int64_t r;             /* R is (sp, r) with leading dimension ldr; 0 if no Psi */
+    int64_t x_p, x_k, x_pp;
+    int64_t ldlin, ldlout, ldr;
+    int64_t psi_q, psi_k, psi_c;   /* element strides of Psi[q,k,c] */
+} ttsk_tt_step_desc;
+int ttsk_tt_step(const ttsk_tt_step_desc *desc, const double *Lin, const double *X,
+                 const double *D, const double *R, double *Lout, double *Psi, int stream);
+/* Omega_mu = L_mu^T R_mu (tensor_train_sketch.py:8-11) is a ttsk_gemm. */
+
+/* ---- hash sampler (the reference's native module) -------------------------
+ * Host-pointer twins of the Cython API (fast_lazy_gaussian.pyx:14,53,156,183);
+ * idx is (m, N) row-major int64/uint64, shape has m entries. */
+int ttsk_hash_u64(uint64_t *host_vals, size_t n);                       /* pyx:13-37, in place */
+int ttsk_inds_to_rand_double(const uint64_t *host_idx, const uint64_t *shape, int m, size_t N,
+                             int rank_min, int rank_max, uint64_t seed, double *host_out);
+int ttsk_inds_to_normal(const int64_t *host_idx, const uint64_t *shape, int m, size_t N,
+                        int rank_min, int rank_max, uint64_t seed, double *host_out /* (N,rank) */);
+int ttsk_inds_to_sparse_sign(const int64_t *host_idx, const uint64_t *shape, int m, size_t N,
+                             int true_rank, int rank_min, int rank_max, int nnz_per_row,
+                             uint64_t seed, int16_t *host_out /* (N, rank_max-rank_min) */);
+/* Device-resident forms used by SparseGaussianDRM / SparseSignDRM.sketch_sparse
+ * (sparse_gaussian_drm.py:29-44, sparse_sign_drm.py:34-51).  idx rows are addressed
+ * as dev_idx + row_order[i]*row_stride so that tensor.T (tensor.py:201-204, reversed
+ * index rows) needs no copy.  Output (N, rank) row-major fp64. */
+int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
+                           const uint64_t *shape, int m, size_t N, int rank_min, int rank_max,
+                           uint64_t seed, double *dev_out, int stream);
+int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
+                         const uint64_t *shape, int m, size_t N, int true_rank, int rank_min,
+                         int rank_max, int nnz_per_row, uint64_t seed, double *dev_out, int stream);
+/* counter-based N(0,1) fill for TensorTrainDRM / DenseGaussianDRM sampling
+ * (tensor.py:358-371 via utils.py:178-227; dense_gaussian_drm.py:50-55): the
+ * reference's streams are not reproducible across hosts, parity is by
+ * injection; this generator is the same hash -> ndtri construction keyed by (seed, i). */
+int ttsk_fill_normal(double *dev_out, size_t n, uint64_t seed, double scale, int stream);
+
+/* ---- sparse-input kernels --------------------------------------------------
+ * TensorTrainDRM.sketch_sparse (tensor_train_drm.py:60-69): per nonzero e,
+ *   v_e <- v_e * D[:, idx[e], :], out (N, rho') row-major; vin NULL for the first mode */
+int ttsk_sparse_ttdrm_step(const double *dev_vin, int64_t rho, const double *dev_core,
+                           int64_t n, int64_t rhop, const int64_t *dev_idx_row, size_t N,
+                           double *dev_vout, int stream);
+/* DenseGaussianDRM.sketch_sparse (dense_gaussian_drm.py:59-66): C-order ravel of the
+ * first m index rows, then column gather of mat (rank, cols): out (N, rank) row-major */
+int ttsk_sparse_densedrm_gather(const double *dev_mat, int64_t rank, int64_t cols,
+                                const int64_t *dev_idx, int64_t row_stride, const int *row_order,
+                                const int64_t *shape, int m, size_t N, double *dev_out, int stream);
+/* sketch_psi_sparse (sparse_sketch.py:8-36,49-69):
+ *   Psi[a, idx[e], c] += val[e] * Lv[e,a] * Rv[e,c]   (Lv/Rv NULL -> rank 1, value 1)
+ * Lv (N,l) and Rv (N,r) row-major as produced above; Psi (l,n,r) contiguous, zeroed by caller. */
+int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, size_t N,
+                    const double *dev_Lv, int64_t l, const double *dev_Rv, int64_t r,
+                    int64_t n, double *dev_psi, int stream);
+/* sketch_omega_sparse (sparse_sketch.py:39-46) is ttsk_gemm with k_scale = entries. */
+
+/* ---- solves ----------------------------------------------------------------
+ * right_mul_pinv / left_mul_pinv (utils.py:98-109; SciPy lstsq -> LAPACK gelsd with
+ * cond = eps): P = pinv(Omega) by one-sided Jacobi SVD on the device, singular values
+ * below rcond*sigma_max dropped (rcond < 0 -> DBL_EPSILON).  Omega is (l, r)
+ * contiguous; P is (r, l) contiguous.  The products A*P / P*B are ttsk_gemm calls. */
+int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
+              int *host_rank /* may be NULL */, int stream);
+/* thin QR of orth_step (sketch_dispatch.py:172, scipy.linalg.qr(mode="economic")):
+ * A (m, n) row-major with m >= n is overwritten by Q (m, n); Householder with LAPACK's
+ * sign convention.  R is not returned (the reference discards it). */
+int ttsk_qr_thin(double *dev_A, int64_t m, int64_t n, int stream);
+
+/* ---- multi-GPU: one RCCL sum of the packed partial sketch ------------------
+ * SketchContainer.__add__ across ranks (sketch_container.py:61-69). */
+int ttsk_comm_unique_id(void *host_id128);                 /* rank 0: 128-byte id */
+int ttsk_comm_init(const void *host_id128, int rank, int nranks);
+int ttsk_comm_allreduce_sum(double *dev_buf, size_t n, int stream);
+int ttsk_comm_reduce_sum(double *dev_buf, size_t n, int root, int stream);
+int ttsk_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSK_H */

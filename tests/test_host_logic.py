@@ -1,0 +1,86 @@
+"""CPU tests: host-side logic of tt_sketch_amd and the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tt_sketch_amd import _native as nat
+from tt_sketch_amd.device import _view_strides
+from tt_sketch_amd.utils import dematricize, matricize, process_tt_rank, trim_ranks
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nat.lib()                      # raises if a symbol of include/ttsk.h is missing
+    names = nat.declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_rank_processing():
+    assert process_tt_rank(3, (4, 5, 6), trim=False) == (3, 3)
+    assert process_tt_rank((2, 9), (4, 5, 6), trim=False) == (2, 9)
+    with pytest.raises(ValueError):
+        process_tt_rank((2, 3, 4), (4, 5, 6), trim=False)
+    assert trim_ranks((4, 5, 6), (100, 100)) == (4, 6)
+    assert trim_ranks((2, 2, 2, 2), (9, 9, 9)) == (2, 4, 2)
+    assert trim_ranks((10, 10, 10), (3, 50)) == (3, 10)
+    assert process_tt_rank(100, (5, 6, 7, 8), trim=True) == (5, 30, 8)
+
+
+def test_matricize_roundtrip():
+    A = np.arange(2 * 3 * 4 * 5.0).reshape(2, 3, 4, 5)
+    for mode in range(4):
+        M = matricize(A, mode)
+        assert M.shape == (A.shape[mode], A.size // A.shape[mode])
+        assert np.array_equal(dematricize(M, mode, A.shape), A)
+    assert matricize(A, range(2), mat_shape=True).shape == (6, 20)
+    assert matricize(A, range(2)).shape == (2, 3, 20)
+
+
+def test_view_strides_rule():
+    assert _view_strides((3, 4, 5), (20, 5, 1), (12, 5)) == (5, 1)
+    assert _view_strides((3, 4, 5), (1, 3, 12), (12, 5)) is None
+    assert _view_strides((1, 7, 4), (1, 1, 7), (7, 4)) == (1, 7)
+    assert _view_strides((6, 5), (5, 1), (2, 3, 5)) == (15, 5, 1)
+
+
+def test_drm_bookkeeping_matches_reference_conventions():
+    from tt_sketch_amd.drm_base import DRM
+    d = DRM((3, 4, 5), (6, 7, 8, 9), transpose=True, seed=12,
+            rank_min=(1, 0, 2), rank_max=(3, 4, 5), true_rank=(3, 4, 5))
+    assert d.rank_min == (2, 0, 1) and d.rank_max == (5, 4, 3) and d.rank == (3, 4, 2)
+    assert d.true_rank == (5, 4, 3)
+    t = d.T
+    assert t.transpose is False and t.rank == (2, 4, 3) and t.rank_min == (1, 0, 2)
+    assert DRM(3, (4, 5), False, seed=2**32 + 5).seed == (2**32 + 5) % (2**32 - 1)
+
+
+def test_container_arithmetic_and_packing():
+    from tt_sketch_amd import SketchContainer
+    rng = np.random.default_rng(0)
+    a = SketchContainer.zero((4, 5, 6), (2, 3), (3, 4))
+    b = SketchContainer([rng.standard_normal(p.shape) for p in a.Psi_cores],
+                        [rng.standard_normal(o.shape) for o in a.Omega_mats])
+    c = (b + b) * 0.5 - b / 1.0
+    assert all(np.allclose(x, 0) for x in c.Psi_cores + c.Omega_mats)
+    assert b.left_rank == (2, 3) and b.right_rank == (3, 4) and b.shape == (4, 5, 6)
+    t = b.T
+    assert t.left_rank == (4, 3) and t.right_rank == (3, 2)
+    buf = b.pack()
+    assert buf.size == sum(x.size for x in b.Psi_cores + b.Omega_mats)
+    r = a.unpack(buf)
+    assert all(np.array_equal(x, y) for x, y in zip(r.Psi_cores + r.Omega_mats,
+                                                     b.Psi_cores + b.Omega_mats))
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU every compute entry point must raise, never fall back."""
+    import tt_sketch_amd as tsa
+    lib = nat.lib()
+    if lib.ttsk_init(0) == 0:
+        pytest.skip("a GPU is present")
+    X = tsa.TensorTrain.random((4, 5, 6), 2, seed=1)
+    with pytest.raises(nat.TtskError):
+        tsa.stream_sketch(X, 2, 3, seed=1)

@@ -1,0 +1,119 @@
+"""ctypes binding of libttsk.so (the C ABI declared in include/ttsk.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no
+device is present every compute entry point raises.
+"""
+import ctypes
+import os
+import re
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int64,
+                    c_size_t, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttsk.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
+
+TTSK_ERR_ARG = -2
+TTSK_ERR_UNSUPPORTED = -3
+NUM_STREAMS = 4
+
+
+class TtskError(RuntimeError):
+    """A HIP / RCCL level failure inside libttsk."""
+
+
+class TtskUnsupported(TtskError):
+    """The fused kernel does not cover this shape (caller composes from ttsk_gemm)."""
+
+
+class GemmDesc(Structure):
+    _fields_ = [(n, c_int64) for n in
+                ("batch", "M", "N", "Ko", "Ki", "a_b", "a_m", "a_ko", "a_ki",
+                 "b_b", "b_ko", "b_ki", "b_n", "c_b", "c_m", "c_n")] + [
+        ("alpha", c_double), ("accumulate", c_int), ("split_k", c_int)]
+
+
+class TTStepDesc(Structure):
+    _fields_ = [(n, c_int64) for n in
+                ("s", "n", "sp", "l", "lp", "r", "x_p", "x_k", "x_pp",
+                 "ldlin", "ldlout", "ldr", "psi_q", "psi_k", "psi_c")]
+
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name include/ttsk.h declares."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(ttsk_[a-z0-9_]+)\s*\(", text)))
+
+
+def _bind(lib):
+    P, I, S = c_void_p, c_int, c_size_t
+    sig = {
+        "ttsk_init": [I], "ttsk_shutdown": [], "ttsk_device_info": [c_char_p, S, POINTER(I), POINTER(S)],
+        "ttsk_malloc": [POINTER(P), S], "ttsk_free": [P], "ttsk_memset": [P, I, S, I],
+        "ttsk_h2d": [P, P, S, I], "ttsk_d2h": [P, P, S, I], "ttsk_d2d": [P, P, S, I],
+        "ttsk_sync": [I], "ttsk_stream_wait": [I, I],
+        "ttsk_timer_start": [I], "ttsk_timer_stop": [I, POINTER(c_float)],
+        "ttsk_graph_begin": [I], "ttsk_graph_end": [I, POINTER(P)], "ttsk_graph_launch": [P, I],
+        "ttsk_graph_free": [P],
+        "ttsk_gemm": [POINTER(GemmDesc), P, P, P, P, I],
+        "ttsk_copy_strided": [P, P, I, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), I],
+        "ttsk_axpby": [P, P, c_double, c_double, S, I],
+        "ttsk_tt_step": [POINTER(TTStepDesc), P, P, P, P, P, P, I],
+        "ttsk_hash_u64": [P, S],
+        "ttsk_inds_to_rand_double": [P, P, I, S, I, I, c_uint64, P],
+        "ttsk_inds_to_normal": [P, P, I, S, I, I, c_uint64, P],
+        "ttsk_inds_to_sparse_sign": [P, P, I, S, I, I, I, I, c_uint64, P],
+        "ttsk_sparse_normal_dev": [P, c_int64, POINTER(I), POINTER(c_uint64), I, S, I, I, c_uint64, P, I],
+        "ttsk_sparse_sign_dev": [P, c_int64, POINTER(I), POINTER(c_uint64), I, S, I, I, I, I, c_uint64, P, I],
+        "ttsk_fill_normal": [P, S, c_uint64, c_double, I],
+        "ttsk_sparse_ttdrm_step": [P, c_int64, P, c_int64, c_int64, P, S, P, I],
+        "ttsk_sparse_densedrm_gather": [P, c_int64, c_int64, P, c_int64, POINTER(I), POINTER(c_int64), I, S, P, I],
+        "ttsk_sparse_psi": [P, P, S, P, c_int64, P, c_int64, c_int64, P, I],
+        "ttsk_pinv": [P, c_int64, c_int64, c_double, P, POINTER(I), I],
+        "ttsk_qr_thin": [P, c_int64, c_int64, I],
+        "ttsk_comm_unique_id": [P], "ttsk_comm_init": [P, I, I],
+        "ttsk_comm_allreduce_sum": [P, S, I], "ttsk_comm_reduce_sum": [P, S, I, I],
+        "ttsk_comm_destroy": [],
+    }
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise TtskError(f"{LIB_PATH} does not export {missing}")
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.ttsk_last_error.restype = c_char_p
+    lib.ttsk_last_error.argtypes = []
+
+
+def lib():
+    """Loads libttsk.so (no device needed) and checks the exported symbol set."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TtskError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "tt_sketch_amd has no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        _bind(handle)
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().ttsk_last_error().decode(errors="replace")
+    if rc == TTSK_ERR_ARG:
+        raise ValueError(msg)
+    if rc == TTSK_ERR_UNSUPPORTED:
+        raise TtskUnsupported(msg)
+    raise TtskError(msg)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))

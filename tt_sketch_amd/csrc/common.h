@@ -1,0 +1,51 @@
+// Shared internals of libttsk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "ttsk.h"
+
+namespace ttsk {
+
+void set_error(const char *fmt, ...);
+hipStream_t stream_of(int s);   // nullptr + error set if invalid / not initialised
+int ensure_init();
+
+#define TTSK_HIP(call)                                                          \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            ttsk::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                \
+            return TTSK_ERR_HIP;                                                \
+        }                                                                       \
+    } while (0)
+
+#define TTSK_ARG(cond, ...)                                                     \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            ttsk::set_error(__VA_ARGS__);                                       \
+            return TTSK_ERR_ARG;                                                \
+        }                                                                       \
+    } while (0)
+
+#define TTSK_STREAM(var, s)                                                     \
+    hipStream_t var = ttsk::stream_of(s);                                       \
+    if (!var) return TTSK_ERR_ARG
+
+#define TTSK_LAUNCH_CHECK()                                                     \
+    TTSK_HIP(hipGetLastError())
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: A lane l holds A[m=l&15][k=l>>4], B lane l holds
+// B[k=l>>4][n=l&15]; D reg j of lane l is D[row=(l>>4)+4j][col=l&15].
+__device__ __forceinline__ v4d mfma16(double a, double b, v4d c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace ttsk

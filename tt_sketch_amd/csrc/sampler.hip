@@ -1,0 +1,355 @@
+// Hash-based lazy sampler on the device: 64-bit mix -> forced-exponent double ->
+// inverse normal CDF, and sparse-sign rows.  Replaces the reference's only native
+// module, tt_sketch/drm/fast_lazy_gaussian.pyx (hash :13-37, rand double :52-105,
+// normal :39-50/:183-202, sparse sign :121-180).  Integer stages are bit-exact;
+// the Gaussian stage follows the Cephes ndtri algorithm that the reference calls
+// through SciPy (pyx:49) and agrees with it to a few ulp (device log/sqrt).
+#include <cmath>
+#include <vector>
+#include "common.h"
+
+namespace ttsk {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t r)
+{
+    r += 0x4BE98134A5976FD3ULL;
+    r ^= r >> 30;
+    r *= 0xBF58476D1CE4E5B9ULL;
+    r ^= r >> 27;
+    r *= 0x94D049BB133111EBULL;
+    r ^= r >> 31;
+    return r;
+}
+
+constexpr int MAX_MODES = 32;
+struct IndexMap {
+    int m;
+    int row_order[MAX_MODES];
+    uint64_t mult[MAX_MODES];  // Fortran-order multipliers with the reference's int32 wrap
+    int64_t row_stride;
+};
+
+// fast_lazy_gaussian.pyx:60-71 -- `cdef int prod` is 32-bit and sign-extends.
+static int make_index_map(const uint64_t *shape, int m, int64_t row_stride, const int *row_order,
+                          IndexMap *im)
+{
+    TTSK_ARG(m >= 1 && m <= MAX_MODES, "hash sampler supports 1..%d index rows, got %d", MAX_MODES, m);
+    im->m = m;
+    im->row_stride = row_stride;
+    int32_t prod = (int32_t)shape[0];
+    for (int i = 0; i < m; ++i) {
+        im->row_order[i] = row_order ? row_order[i] : i;
+        if (i == 0) { im->mult[0] = 1; continue; }
+        im->mult[i] = (uint64_t)(int64_t)prod;
+        prod = (int32_t)((uint64_t)(int64_t)prod * shape[i]);
+    }
+    return TTSK_OK;
+}
+
+__device__ __forceinline__ uint64_t flat_index(const int64_t *idx, const IndexMap &im, size_t e)
+{
+    uint64_t f = 0;
+    for (int i = 0; i < im.m; ++i)
+        f += (uint64_t)idx[(int64_t)im.row_order[i] * im.row_stride + (int64_t)e] * im.mult[i];
+    return f;
+}
+
+__device__ __forceinline__ uint64_t rand_bits(uint64_t flat, int col, uint64_t seed)
+{
+    uint64_t salt = mix64((uint64_t)col) + seed;
+    uint64_t h = mix64(flat + salt);
+    return (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;  // exponent field 001x..., pyx:91-101
+}
+
+// frexp(x)*2-1 for a normal positive double: the 52 mantissa bits as a fraction in [0,1)
+__device__ __forceinline__ double mant_unit(uint64_t bits)
+{
+    return __longlong_as_double((bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL) - 1.0;
+}
+
+__device__ double ndtri_dev(double y0)
+{
+    const double s2pi = 2.50662827463100050242E0;
+    const double expm2 = 0.13533528323661269189;
+    if (y0 == 0.0) return -INFINITY;
+    if (y0 == 1.0) return INFINITY;
+    int code = 1;
+    double y = y0;
+    if (y > 1.0 - expm2) { y = 1.0 - y; code = 0; }
+    if (y > expm2) {
+        y -= 0.5;
+        double y2 = y * y;
+        double p = -5.99633501014107895267E1;
+        p = p * y2 + 9.80010754185999661536E1;
+        p = p * y2 - 5.66762857469070293439E1;
+        p = p * y2 + 1.39312609387279679503E1;
+        p = p * y2 - 1.23916583867381258016E0;
+        double q = y2 + 1.95448858338141759834E0;
+        q = q * y2 + 4.67627912898881538453E0;
+        q = q * y2 + 8.63602421390890590575E1;
+        q = q * y2 - 2.25462687854119370527E2;
+        q = q * y2 + 2.00260212380060660359E2;
+        q = q * y2 - 8.20372256168333339912E1;
+        q = q * y2 + 1.59056225126211695515E1;
+        q = q * y2 - 1.18331621121330003142E0;
+        double x = y + y * (y2 * p / q);
+        return x * s2pi;
+    }
+    double x = sqrt(-2.0 * log(y));
+    double x0 = x - log(x) / x;
+    double z = 1.0 / x;
+    double p, q;
+    if (x < 8.0) {
+        p = 4.05544892305962419923E0;
+        p = p * z + 3.15251094599893866154E1;
+        p = p * z + 5.71628192246421288162E1;
+        p = p * z + 4.40805073893200834700E1;
+        p = p * z + 1.46849561928858024014E1;
+        p = p * z + 2.18663306850790267539E0;
+        p = p * z - 1.40256079171354495875E-1;
+        p = p * z - 3.50424626827848203418E-2;
+        p = p * z - 8.57456785154685413611E-4;
+        q = z + 1.57799883256466749731E1;
+        q = q * z + 4.53907635128879210584E1;
+        q = q * z + 4.13172038254672030440E1;
+        q = q * z + 1.50425385692907503408E1;
+        q = q * z + 2.50464946208309415979E0;
+        q = q * z - 1.42182922854787788574E-1;
+        q = q * z - 3.80806407691578277194E-2;
+        q = q * z - 9.33259480895457427372E-4;
+    } else {
+        p = 3.23774891776946035970E0;
+        p = p * z + 6.91522889068984211695E0;
+        p = p * z + 3.93881025292474443415E0;
+        p = p * z + 1.33303460815807542389E0;
+        p = p * z + 2.01485389549179081538E-1;
+        p = p * z + 1.23716634817820021358E-2;
+        p = p * z + 3.01581553508235416007E-4;
+        p = p * z + 2.65806974686737550832E-6;
+        p = p * z + 6.23974539184983293730E-9;
+        q = z + 6.02427039364742014255E0;
+        q = q * z + 3.67983563856160859403E0;
+        q = q * z + 1.37702099489081330271E0;
+        q = q * z + 2.16236993594496635890E-1;
+        q = q * z + 1.34204006088543189037E-2;
+        q = q * z + 3.28014464682127739104E-4;
+        q = q * z + 2.89247864745380683936E-6;
+        q = q * z + 6.79019408009981274425E-9;
+    }
+    double x1 = z * p / q;
+    x = x0 - x1;
+    return code ? -x : x;
+}
+
+__global__ void hash_kernel(uint64_t *v, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        v[i] = mix64(v[i]);
+}
+
+// mode 0: raw forced-exponent bits as double, mode 1: N(0,1)
+template <int MODE>
+__global__ void sample_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t N, int rank_min,
+                              int rank, uint64_t seed, double *__restrict__ out)
+{
+    const size_t tot = N * (size_t)rank;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < tot;
+         g += (size_t)gridDim.x * blockDim.x) {
+        size_t e = g / rank;
+        int j = (int)(g - e * rank);
+        uint64_t bits = rand_bits(flat_index(idx, im, e), rank_min + j, seed);
+        out[g] = MODE == 0 ? __longlong_as_double(bits) : ndtri_dev(mant_unit(bits));
+    }
+}
+
+// One thread per index row.  The full-length row lives in a scratch plane laid out
+// [position][row] so that neighbouring threads touch neighbouring bytes.
+template <typename OUT>
+__global__ void sign_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t N, int rank, int nnz,
+                            int rank_min, int rank_max, uint64_t seed, int8_t *__restrict__ ws,
+                            OUT *__restrict__ out)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const uint64_t flat = flat_index(idx, im, e);
+    for (int j = 0; j < rank; ++j) ws[(size_t)j * N + e] = 0;
+    for (int j = 0; j < nnz; ++j) {
+        uint64_t bits = rand_bits(flat, j, seed);
+        int ex = (int)((bits >> 52) & 0x7FF) - 1022;  // frexp exponent
+        int par = ((ex % 2) + 2) % 2;                 // Python-style modulo (pyx:145)
+        ws[(size_t)j * N + e] = (int8_t)(par * 2 - 1);
+    }
+    for (int j = 0; j < nnz; ++j) {
+        double u = mant_unit(rand_bits(flat, j, seed));
+        int pick = (int)(u * (double)(rank - j) + (double)j);
+        int8_t a = ws[(size_t)j * N + e], b = ws[(size_t)pick * N + e];
+        ws[(size_t)j * N + e] = b;
+        ws[(size_t)pick * N + e] = a;
+    }
+    const int w = rank_max - rank_min;
+    for (int j = 0; j < w; ++j) out[e * (size_t)w + j] = (OUT)ws[(size_t)(rank_min + j) * N + e];
+}
+
+__global__ void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t h = mix64((uint64_t)i + key);
+        h = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
+        double u = mant_unit(h);
+        if (u == 0.0) u = 0x1p-53;
+        out[i] = scale * ndtri_dev(u);
+    }
+}
+
+static unsigned grid_for(size_t n, unsigned block = 256, unsigned cap = 16384)
+{
+    size_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+template <typename OUT>
+static int sign_dev(const int64_t *dev_idx, const IndexMap &im, size_t N, int true_rank, int rank_min,
+                    int rank_max, int nnz, uint64_t seed, OUT *dev_out, hipStream_t st)
+{
+    TTSK_ARG(nnz >= 0 && nnz <= true_rank, "sparse sign: nnz_per_row %d not in [0, %d]", nnz, true_rank);
+    TTSK_ARG(0 <= rank_min && rank_min <= rank_max && rank_max <= true_rank,
+             "sparse sign: bad rank slice [%d,%d) of %d", rank_min, rank_max, true_rank);
+    if (N == 0 || rank_max == rank_min) return TTSK_OK;
+    int8_t *ws = nullptr;
+    TTSK_HIP(hipMallocAsync((void **)&ws, N * (size_t)true_rank, st));
+    hipLaunchKernelGGL((sign_kernel<OUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dev_idx, im,
+                       N, true_rank, nnz, rank_min, rank_max, seed, ws, dev_out);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, st);
+    TTSK_HIP(e);
+    return TTSK_OK;
+}
+
+}  // namespace ttsk
+
+using namespace ttsk;
+
+extern "C" {
+
+int ttsk_hash_u64(uint64_t *host_vals, size_t n)
+{
+    TTSK_STREAM(st, 0);
+    if (n == 0) return TTSK_OK;
+    TTSK_ARG(host_vals, "ttsk_hash_u64: NULL");
+    uint64_t *d = nullptr;
+    TTSK_HIP(hipMalloc((void **)&d, n * 8));
+    hipError_t e = hipMemcpyAsync(d, host_vals, n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hash_kernel, dim3(grid_for(n)), dim3(256), 0, st, d, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_vals, d, n * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    TTSK_HIP(e);
+    return TTSK_OK;
+}
+
+int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
+                           const uint64_t *shape, int m, size_t N, int rank_min, int rank_max,
+                           uint64_t seed, double *dev_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(rank_max >= rank_min && rank_min >= 0, "bad rank slice [%d,%d)", rank_min, rank_max);
+    IndexMap im;
+    int rc = make_index_map(shape, m, row_stride, row_order, &im);
+    if (rc) return rc;
+    size_t tot = N * (size_t)(rank_max - rank_min);
+    if (tot == 0) return TTSK_OK;
+    hipLaunchKernelGGL((sample_kernel<1>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, dev_idx,
+                       im, N, rank_min, rank_max - rank_min, seed, dev_out);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
+                         const uint64_t *shape, int m, size_t N, int true_rank, int rank_min,
+                         int rank_max, int nnz_per_row, uint64_t seed, double *dev_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    IndexMap im;
+    int rc = make_index_map(shape, m, row_stride, row_order, &im);
+    if (rc) return rc;
+    return sign_dev<double>(dev_idx, im, N, true_rank, rank_min, rank_max, nnz_per_row, seed, dev_out, st);
+}
+
+static int host_sample(const void *host_idx, const uint64_t *shape, int m, size_t N, int rank_min,
+                       int rank_max, uint64_t seed, void *host_out, int mode, int true_rank, int nnz)
+{
+    TTSK_STREAM(st, 0);
+    TTSK_ARG(rank_max >= rank_min && rank_min >= 0, "bad rank slice [%d,%d)", rank_min, rank_max);
+    IndexMap im;
+    int rc = make_index_map(shape, m, (int64_t)N, nullptr, &im);
+    if (rc) return rc;
+    const int w = rank_max - rank_min;
+    const size_t tot = N * (size_t)w;
+    if (tot == 0) return TTSK_OK;
+    TTSK_ARG(host_idx && host_out, "hash sampler: NULL buffer");
+    int64_t *didx = nullptr;
+    void *dout = nullptr;
+    const size_t out_bytes = tot * (mode == 2 ? sizeof(int16_t) : sizeof(double));
+    TTSK_HIP(hipMalloc((void **)&didx, (size_t)m * N * 8));
+    hipError_t e = hipMalloc(&dout, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(didx, host_idx, (size_t)m * N * 8, hipMemcpyHostToDevice, st);
+    int status = TTSK_OK;
+    if (e == hipSuccess) {
+        if (mode == 0)
+            hipLaunchKernelGGL((sample_kernel<0>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, didx,
+                               im, N, rank_min, w, seed, (double *)dout);
+        else if (mode == 1)
+            hipLaunchKernelGGL((sample_kernel<1>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, didx,
+                               im, N, rank_min, w, seed, (double *)dout);
+        else
+            status = sign_dev<int16_t>(didx, im, N, true_rank, rank_min, rank_max, nnz, seed, (int16_t *)dout, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && status == TTSK_OK)
+        e = hipMemcpyAsync(host_out, dout, out_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(didx);
+    (void)hipFree(dout);
+    if (status != TTSK_OK) return status;
+    TTSK_HIP(e);
+    return TTSK_OK;
+}
+
+int ttsk_inds_to_rand_double(const uint64_t *host_idx, const uint64_t *shape, int m, size_t N,
+                             int rank_min, int rank_max, uint64_t seed, double *host_out)
+{
+    return host_sample(host_idx, shape, m, N, rank_min, rank_max, seed, host_out, 0, 0, 0);
+}
+
+int ttsk_inds_to_normal(const int64_t *host_idx, const uint64_t *shape, int m, size_t N, int rank_min,
+                        int rank_max, uint64_t seed, double *host_out)
+{
+    return host_sample(host_idx, shape, m, N, rank_min, rank_max, seed, host_out, 1, 0, 0);
+}
+
+int ttsk_inds_to_sparse_sign(const int64_t *host_idx, const uint64_t *shape, int m, size_t N,
+                             int true_rank, int rank_min, int rank_max, int nnz_per_row, uint64_t seed,
+                             int16_t *host_out)
+{
+    return host_sample(host_idx, shape, m, N, rank_min, rank_max, seed, host_out, 2, true_rank,
+                       nnz_per_row);
+}
+
+int ttsk_fill_normal(double *dev_out, size_t n, uint64_t seed, double scale, int stream)
+{
+    TTSK_STREAM(st, stream);
+    if (n == 0) return TTSK_OK;
+    uint64_t key = mix64(seed ^ 0x9E3779B97F4A7C15ULL);
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for(n, 256, 1u << 16)), dim3(256), 0, st, dev_out, n,
+                       key, scale);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+}  // extern "C"

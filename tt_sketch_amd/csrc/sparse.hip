@@ -1,0 +1,192 @@
+// Sparse (COO) input kernels: gather-chain for a TT DRM, column gather for a dense
+// Gaussian DRM, and the Psi scatter.  All HBM-bound streaming of (nnz x rank) panels.
+#include "common.h"
+
+namespace ttsk {
+
+// TensorTrainDRM.sketch_sparse, tensor_train_drm.py:60-69.
+// vout[e,b] = sum_a vin[e,a] * D[a, idx[e], b]; one thread per (e,b), b fastest so that
+// the core slice row D[a,k,:] and the output row are read/written contiguously.
+__global__ void sparse_ttdrm_kernel(const double *__restrict__ vin, int64_t rho,
+                                    const double *__restrict__ core, int64_t n, int64_t rhop,
+                                    const int64_t *__restrict__ idx, size_t N, double *__restrict__ vout)
+{
+    const size_t tot = N * (size_t)rhop;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < tot;
+         g += (size_t)gridDim.x * blockDim.x) {
+        size_t e = g / rhop;
+        int64_t b = (int64_t)(g - e * rhop);
+        int64_t k = idx[e];
+        const double *c = core + k * rhop + b;
+        double acc = 0.0;
+        if (vin) {
+            const double *v = vin + e * rho;
+            for (int64_t a = 0; a < rho; ++a) acc = fma(v[a], c[a * n * rhop], acc);
+        } else {
+            acc = c[0];
+        }
+        vout[g] = acc;
+    }
+}
+
+constexpr int MAX_MODES = 32;
+struct RavelMap {
+    int m;
+    int row_order[MAX_MODES];
+    int64_t mult[MAX_MODES];  // C-order multipliers (np.ravel_multi_index)
+    int64_t row_stride;
+};
+
+// DenseGaussianDRM.sketch_sparse, dense_gaussian_drm.py:59-66.
+__global__ void sparse_dense_gather_kernel(const double *__restrict__ mat, int64_t rank, int64_t cols,
+                                           const int64_t *__restrict__ idx, RavelMap rm, size_t N,
+                                           double *__restrict__ out)
+{
+    const size_t tot = N * (size_t)rank;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < tot;
+         g += (size_t)gridDim.x * blockDim.x) {
+        size_t e = g / rank;
+        int64_t j = (int64_t)(g - e * rank);
+        int64_t flat = 0;
+        for (int i = 0; i < rm.m; ++i)
+            flat += idx[(int64_t)rm.row_order[i] * rm.row_stride + (int64_t)e] * rm.mult[i];
+        out[g] = mat[j * cols + flat];
+    }
+}
+
+// sketch_psi_sparse, sparse_sketch.py:8-36,49-69 (scatter form).
+// Psi[a, idx[e], c] += val[e] * Lv[e,a] * Rv[e,c].
+// One workgroup walks a contiguous chunk of nonzeros; thread t owns output pair
+// (a,c) = (t / r, t % r) (looping if l*r > blockDim) and keeps a running partial sum
+// while consecutive nonzeros fall in the same slice k, flushing with one fp64 atomic
+// per slice change.  For mode-sorted input (ttsk sorts once per tensor and mode) this
+// is a segmented reduction with O(#slices) atomics per chunk; for unsorted input it
+// degrades gracefully to one atomic per nonzero per pair.
+__global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restrict__ val,
+                                                         const int64_t *__restrict__ idx,
+                                                         const int64_t *__restrict__ perm, size_t N,
+                                                         const double *__restrict__ Lv, int64_t l,
+                                                         const double *__restrict__ Rv, int64_t r, int64_t n,
+                                                         double *__restrict__ psi, size_t chunk)
+{
+    constexpr int TB = 64;  // nonzeros staged per LDS batch
+    extern __shared__ double sm[];
+    double *sL = sm;                 // TB * l
+    double *sR = sL + TB * l;        // TB * r
+    double *sV = sR + TB * r;        // TB
+    int64_t *sK = (int64_t *)(sV + TB);
+    const size_t beg = (size_t)blockIdx.x * chunk;
+    const size_t end = beg + chunk < N ? beg + chunk : N;
+    const int64_t pairs = l * r;
+    for (int64_t p0 = 0; p0 < pairs; p0 += blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool live = p < pairs;
+        const int64_t a = live ? p / r : 0, c = live ? p - (p / r) * r : 0;
+        double acc = 0.0;
+        int64_t cur = -1;
+        for (size_t b0 = beg; b0 < end; b0 += TB) {
+            const int cnt = (int)((end - b0) < TB ? (end - b0) : TB);
+            __syncthreads();
+            for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+                size_t e = perm ? (size_t)perm[b0 + t] : b0 + t;
+                sV[t] = val[e];
+                sK[t] = idx[e];
+            }
+            for (int64_t t = threadIdx.x; t < (int64_t)cnt * l; t += blockDim.x) {
+                int64_t w = t / l, a2 = t - w * l;
+                size_t e = perm ? (size_t)perm[b0 + w] : b0 + w;
+                sL[t] = Lv ? Lv[e * l + a2] : 1.0;
+            }
+            for (int64_t t = threadIdx.x; t < (int64_t)cnt * r; t += blockDim.x) {
+                int64_t w = t / r, c2 = t - w * r;
+                size_t e = perm ? (size_t)perm[b0 + w] : b0 + w;
+                sR[t] = Rv ? Rv[e * r + c2] : 1.0;
+            }
+            __syncthreads();
+            if (live) {
+                for (int t = 0; t < cnt; ++t) {
+                    int64_t k = sK[t];
+                    if (k != cur) {
+                        if (cur >= 0 && acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
+                        acc = 0.0;
+                        cur = k;
+                    }
+                    acc = fma(sV[t] * sL[t * l + a], sR[t * r + c], acc);
+                }
+            }
+        }
+        if (live && cur >= 0 && acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
+    }
+}
+
+}  // namespace ttsk
+
+using namespace ttsk;
+
+static unsigned grid_for(size_t n, unsigned cap)
+{
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+extern "C" {
+
+int ttsk_sparse_ttdrm_step(const double *dev_vin, int64_t rho, const double *dev_core, int64_t n,
+                           int64_t rhop, const int64_t *dev_idx_row, size_t N, double *dev_vout,
+                           int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_core && dev_idx_row && dev_vout, "ttsk_sparse_ttdrm_step: NULL argument");
+    TTSK_ARG(rho >= 1 && rhop >= 1 && n >= 1, "ttsk_sparse_ttdrm_step: bad core shape");
+    TTSK_ARG(dev_vin || rho == 1, "ttsk_sparse_ttdrm_step: first mode needs rho == 1");
+    if (N == 0) return TTSK_OK;
+    hipLaunchKernelGGL(sparse_ttdrm_kernel, dim3(grid_for(N * (size_t)rhop, 1u << 20)), dim3(256), 0, st,
+                       dev_vin, rho, dev_core, n, rhop, dev_idx_row, N, dev_vout);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_sparse_densedrm_gather(const double *dev_mat, int64_t rank, int64_t cols, const int64_t *dev_idx,
+                                int64_t row_stride, const int *row_order, const int64_t *shape, int m,
+                                size_t N, double *dev_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(m >= 1 && m <= MAX_MODES, "ttsk_sparse_densedrm_gather: %d index rows unsupported", m);
+    RavelMap rm;
+    rm.m = m;
+    rm.row_stride = row_stride;
+    int64_t mult = 1;
+    for (int i = m - 1; i >= 0; --i) {
+        rm.mult[i] = mult;
+        mult *= shape[i];
+        rm.row_order[i] = row_order ? row_order[i] : i;
+    }
+    TTSK_ARG(mult == cols, "ttsk_sparse_densedrm_gather: matrix has %lld columns, index space %lld",
+             (long long)cols, (long long)mult);
+    if (N == 0 || rank == 0) return TTSK_OK;
+    hipLaunchKernelGGL(sparse_dense_gather_kernel, dim3(grid_for(N * (size_t)rank, 1u << 20)), dim3(256), 0,
+                       st, dev_mat, rank, cols, dev_idx, rm, N, dev_out);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, size_t N, const double *dev_Lv,
+                    int64_t l, const double *dev_Rv, int64_t r, int64_t n, double *dev_psi, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_val && dev_idx_row && dev_psi, "ttsk_sparse_psi: NULL argument");
+    TTSK_ARG(l >= 1 && r >= 1 && n >= 1, "ttsk_sparse_psi: bad shape");
+    if (N == 0) return TTSK_OK;
+    const size_t lds = (size_t)64 * (l + r + 2) * 8;
+    TTSK_ARG(lds <= 64 * 1024, "ttsk_sparse_psi: l + r = %lld too large for the staging buffer",
+             (long long)(l + r));
+    size_t chunk = 2048;
+    size_t blocks = (N + chunk - 1) / chunk;
+    hipLaunchKernelGGL(sparse_psi_kernel, dim3((unsigned)blocks), dim3(256), lds, st, dev_val, dev_idx_row,
+                       (const int64_t *)nullptr, N, dev_Lv, l, dev_Rv, r, n, dev_psi, chunk);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,413 @@
+"""Device arrays and the strided contraction front end of libttsk.
+
+``DevArray`` is a strided view on HBM owned by the library (ttsk_malloc).  It
+supports the few NumPy idioms the sketch path uses -- ``.T``, ``transpose``,
+``reshape``, basic slicing, ``np.asarray(x)`` -- as zero-copy views, so that
+``Tensor.T`` (tensor.py:311-313 and friends in the reference), the
+``rank_min:rank_max`` column slices (tensor_train_drm.py:88) and the
+unfoldings (utils.py:63-83) never move data.
+
+``contract("ij,jkl->ikl", A, B)`` lowers a two-operand einsum onto the MFMA
+contraction kernel (ttsk_gemm): index letters are classified into batch / M /
+N / K groups and merged into single strided dimensions.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+_F64 = np.dtype(np.float64)
+
+
+class _Buffer:
+    """Owns one ttsk_malloc allocation."""
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        nat.call("ttsk_malloc", ctypes.byref(p), ctypes.c_size_t(max(int(nbytes), 8)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                nat.lib().ttsk_free(ctypes.c_void_p(self.ptr))
+        except Exception:  # interpreter shutdown
+            pass
+        self.ptr = None
+
+
+def _c_strides(shape):
+    st, acc = [], 1
+    for n in reversed(shape):
+        st.append(acc)
+        acc *= int(n)
+    return tuple(reversed(st))
+
+
+class DevArray:
+    """Strided fp64 / int64 array in device memory (strides in elements)."""
+    __slots__ = ("buf", "offset", "shape", "strides", "dtype")
+    __array_priority__ = 100
+
+    def __init__(self, buf, offset, shape, strides, dtype=_F64):
+        self.buf = buf
+        self.offset = int(offset)
+        self.shape = tuple(int(s) for s in shape)
+        self.strides = tuple(int(s) for s in strides)
+        self.dtype = np.dtype(dtype)
+
+    # ---- construction
+    @classmethod
+    def empty(cls, shape, dtype=_F64) -> "DevArray":
+        shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
+        n = int(np.prod(shape, dtype=np.int64))
+        return cls(_Buffer(n * np.dtype(dtype).itemsize), 0, shape, _c_strides(shape), dtype)
+
+    @classmethod
+    def zeros(cls, shape, dtype=_F64, stream=0) -> "DevArray":
+        a = cls.empty(shape, dtype)
+        if a.size:
+            nat.call("ttsk_memset", ctypes.c_void_p(a.ptr), 0, ctypes.c_size_t(a.size * a.dtype.itemsize), stream)
+        return a
+
+    @classmethod
+    def from_host(cls, arr, dtype=None, stream=0) -> "DevArray":
+        arr = np.ascontiguousarray(arr, dtype=dtype if dtype is not None else getattr(arr, "dtype", None))
+        if arr.dtype not in (np.float64, np.int64, np.uint64):
+            arr = arr.astype(np.float64)
+        a = cls.empty(arr.shape, arr.dtype)
+        if arr.size:
+            nat.call("ttsk_h2d", ctypes.c_void_p(a.ptr), ctypes.c_void_p(arr.ctypes.data),
+                     ctypes.c_size_t(arr.nbytes), stream)
+        return a
+
+    # ---- basic properties
+    @property
+    def ptr(self) -> int:
+        return self.buf.ptr + self.offset * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def is_contiguous(self) -> bool:
+        exp = 1
+        for n, s in zip(reversed(self.shape), reversed(self.strides)):
+            if n != 1 and s != exp:
+                return False
+            exp *= n
+        return True
+
+    def __repr__(self):
+        return f"<DevArray {self.dtype} shape={self.shape} strides={self.strides}>"
+
+    def __len__(self):
+        return self.shape[0]
+
+    # ---- views
+    @property
+    def T(self) -> "DevArray":
+        return DevArray(self.buf, self.offset, self.shape[::-1], self.strides[::-1], self.dtype)
+
+    def transpose(self, *axes) -> "DevArray":
+        if len(axes) == 1 and not np.isscalar(axes[0]):
+            axes = tuple(axes[0])
+        if not axes:
+            return self.T
+        return DevArray(self.buf, self.offset, [self.shape[a] for a in axes],
+                        [self.strides[a] for a in axes], self.dtype)
+
+    def reshape(self, *shape) -> "DevArray":
+        if len(shape) == 1 and not np.isscalar(shape[0]):
+            shape = tuple(shape[0])
+        shape = list(int(s) for s in shape)
+        if -1 in shape:
+            k = shape.index(-1)
+            rest = int(np.prod([s for i, s in enumerate(shape) if i != k], dtype=np.int64))
+            shape[k] = self.size // rest if rest else 0
+        if int(np.prod(shape, dtype=np.int64)) != self.size:
+            raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
+        st = _view_strides(self.shape, self.strides, shape)
+        if st is None:
+            return self.contiguous().reshape(shape)
+        return DevArray(self.buf, self.offset, shape, st, self.dtype)
+
+    def __getitem__(self, key) -> "DevArray":
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = [k is Ellipsis for k in key].index(True)
+            fill = (slice(None),) * (self.ndim - (len(key) - 1 - sum(k is None for k in key)))
+            key = key[:i] + fill + key[i + 1:]
+        off, shape, strides, ax = self.offset, [], [], 0
+        for k in key:
+            if k is None:
+                shape.append(1)
+                strides.append(0)
+                continue
+            n, s = self.shape[ax], self.strides[ax]
+            if isinstance(k, slice):
+                a, b, step = k.indices(n)
+                if step != 1:
+                    raise IndexError("DevArray supports unit-step slices only")
+                b = max(a, b)
+                off += a * s
+                shape.append(b - a)
+                strides.append(s)
+            else:
+                k = int(k)
+                if k < 0:
+                    k += n
+                if not 0 <= k < n:
+                    raise IndexError("index out of range")
+                off += k * s
+            ax += 1
+        shape += self.shape[ax:]
+        strides += self.strides[ax:]
+        return DevArray(self.buf, off, shape, strides, self.dtype)
+
+    # ---- data movement
+    def contiguous(self, stream=0) -> "DevArray":
+        if self.is_contiguous():
+            return self
+        if self.dtype != _F64:
+            raise ValueError("strided copies are implemented for fp64 only")
+        out = DevArray.empty(self.shape, self.dtype)
+        copy_into(out, self, stream)
+        return out
+
+    def copy(self, stream=0) -> "DevArray":
+        out = DevArray.empty(self.shape, self.dtype)
+        if self.size:
+            if self.is_contiguous():
+                nat.call("ttsk_d2d", ctypes.c_void_p(out.ptr), ctypes.c_void_p(self.ptr),
+                         ctypes.c_size_t(self.size * self.dtype.itemsize), stream)
+            else:
+                copy_into(out, self, stream)
+        return out
+
+    def get(self, stream=0) -> np.ndarray:
+        src = self.contiguous(stream)
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.size:
+            nat.call("ttsk_d2h", ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(src.ptr),
+                     ctypes.c_size_t(out.nbytes), stream)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def fill_zero(self, stream=0):
+        if not self.is_contiguous():
+            raise ValueError("fill_zero needs a contiguous array")
+        if self.size:
+            nat.call("ttsk_memset", ctypes.c_void_p(self.ptr), 0,
+                     ctypes.c_size_t(self.size * self.dtype.itemsize), stream)
+        return self
+
+
+def _view_strides(shape, strides, new_shape) -> Optional[Tuple[int, ...]]:
+    """Strides of a reshape that needs no copy, or None (NumPy's no-copy rule)."""
+    old = [(n, s) for n, s in zip(shape, strides) if n != 1]
+    new_strides = [0] * len(new_shape)
+    if int(np.prod(new_shape, dtype=np.int64)) == 0:
+        return _c_strides(new_shape)
+    oi = 0
+    ni = 0
+    nn = len(new_shape)
+    while ni < nn:
+        if new_shape[ni] == 1:
+            new_strides[ni] = 0
+            ni += 1
+            continue
+        if oi >= len(old):
+            return None
+        # gather a run of old dims and new dims with equal products
+        op, np_ = old[oi][0], new_shape[ni]
+        oj, nj = oi + 1, ni + 1
+        while op != np_:
+            if op < np_:
+                if oj >= len(old):
+                    return None
+                op *= old[oj][0]
+                oj += 1
+            else:
+                while nj < nn and new_shape[nj] == 1:
+                    nj += 1
+                if nj >= nn:
+                    return None
+                np_ *= new_shape[nj]
+                nj += 1
+        # old dims oi..oj must be mutually contiguous
+        for k in range(oi, oj - 1):
+            if old[k][1] != old[k + 1][1] * old[k + 1][0]:
+                return None
+        st = old[oj - 1][1]
+        for k in range(nj - 1, ni - 1, -1):
+            new_strides[k] = st if new_shape[k] != 1 else 0
+            st *= new_shape[k]
+        oi, ni = oj, nj
+    if oi != len(old):
+        return None
+    return tuple(new_strides)
+
+
+def copy_into(dst: DevArray, src: DevArray, stream=0):
+    if dst.shape != src.shape:
+        raise ValueError(f"copy_into: shape {src.shape} -> {dst.shape}")
+    if src.size == 0:
+        return
+    # drop unit dims, keep at most 5
+    dims = [(n, d, s) for n, d, s in zip(src.shape, dst.strides, src.strides) if n != 1]
+    merged = []
+    for n, d, s in dims:  # merge neighbours that are contiguous in both
+        if merged and merged[-1][1] == d * n and merged[-1][2] == s * n:
+            pn, pd, ps = merged[-1]
+            merged[-1] = (pn * n, d, s)
+        else:
+            merged.append((n, d, s))
+    if len(merged) > 5:
+        raise ValueError("copy_into supports at most 5 non-mergeable dimensions")
+    nd = len(merged)
+    A = (ctypes.c_int64 * max(nd, 1))
+    nat.call("ttsk_copy_strided", ctypes.c_void_p(dst.ptr), ctypes.c_void_p(src.ptr), nd,
+             A(*[m[0] for m in merged]), A(*[m[1] for m in merged]), A(*[m[2] for m in merged]), stream)
+
+
+def as_dev(x, stream=0) -> DevArray:
+    """DevArray as is; NumPy arrays (e.g. from a user-defined DRM) are uploaded."""
+    if isinstance(x, DevArray):
+        return x
+    return DevArray.from_host(np.asarray(x, dtype=np.float64), stream=stream)
+
+
+def to_host(x) -> np.ndarray:
+    return x.get() if isinstance(x, DevArray) else np.asarray(x)
+
+
+def sync(stream=-1):
+    nat.call("ttsk_sync", stream)
+
+
+# ------------------------------------------------------------------ contraction
+def _merge(letters, size, *stride_maps):
+    """Merge an ordered index group into one (extent, stride per operand) or None."""
+    letters = [c for c in letters if size[c] != 1]
+    if not letters:
+        return 1, tuple(0 for _ in stride_maps)
+    for sm in stride_maps:
+        for x, y in zip(letters[:-1], letters[1:]):
+            if sm[x] != sm[y] * size[y]:
+                return None
+    ext = 1
+    for c in letters:
+        ext *= size[c]
+    return ext, tuple(sm[letters[-1]] for sm in stride_maps)
+
+
+def contract(spec: str, A: DevArray, B: DevArray, out: Optional[DevArray] = None, alpha: float = 1.0,
+             accumulate: bool = False, k_scale: Optional[DevArray] = None, stream: int = 0,
+             split_k: int = 0, _depth: int = 0) -> DevArray:
+    """Two-operand einsum ``"<A idx>,<B idx>-><C idx>"`` on the device."""
+    lhs, co = spec.replace(" ", "").split("->")
+    ia, ib = lhs.split(",")
+    if len(ia) != A.ndim or len(ib) != B.ndim:
+        raise ValueError(f"contract {spec}: operand ranks {A.ndim}, {B.ndim}")
+    size = {}
+    for idx, arr in ((ia, A), (ib, B)):
+        for c, n in zip(idx, arr.shape):
+            if size.setdefault(c, n) != n:
+                raise ValueError(f"contract {spec}: extent mismatch on '{c}'")
+    out_shape = tuple(size[c] for c in co)
+    if out is None:
+        out = DevArray.empty(out_shape)
+        accumulate = False
+    elif out.shape != out_shape:
+        raise ValueError(f"contract {spec}: out has shape {out.shape}, expected {out_shape}")
+    if out.size == 0:
+        return out
+    sa = dict(zip(ia, A.strides))
+    sb = dict(zip(ib, B.strides))
+    sc = dict(zip(co, out.strides))
+    batch = [c for c in co if c in sa and c in sb]
+    Mg = [c for c in co if c in sa and c not in sb]
+    Ng = [c for c in co if c in sb and c not in sa]
+    Kg = [c for c in ia if c in sb and c not in sc]
+    extra = [c for c in ia + ib if c not in co and not (c in sa and c in sb)]
+    if extra:
+        raise ValueError(f"contract {spec}: index '{extra[0]}' is summed in one operand only")
+
+    mb = _merge(batch, size, sa, sb, sc)
+    mm = _merge(Mg, size, sa, sc)
+    mn = _merge(Ng, size, sb, sc)
+    # K: try single merged dim (any order), else two dims
+    Kn = [c for c in Kg if size[c] != 1]
+    kplan = None
+    import itertools
+    for perm in itertools.permutations(Kn):
+        m = _merge(list(perm), size, sa, sb)
+        if m is not None:
+            kplan = (1, 0, 0, m[0], m[1][0], m[1][1])
+            break
+    if kplan is None:
+        for perm in itertools.permutations(Kn):
+            for cut in range(1, len(perm)):
+                m1 = _merge(list(perm[:cut]), size, sa, sb)
+                m2 = _merge(list(perm[cut:]), size, sa, sb)
+                if m1 is not None and m2 is not None:
+                    kplan = (m1[0], m1[1][0], m1[1][1], m2[0], m2[1][0], m2[1][1])
+                    break
+            if kplan:
+                break
+    if mb is None or mm is None or mn is None or kplan is None:
+        # materialise the offending operand(s) in [batch, M, K] / [batch, K, N] order and retry
+        if _depth > 0:
+            raise ValueError(f"contract {spec}: cannot be lowered onto the strided GEMM")
+        if not out.is_contiguous():
+            raise ValueError(f"contract {spec}: a strided `out` needs mergeable index groups")
+        oa, ob = batch + Mg + Kg, batch + Kg + Ng
+        A2 = A.transpose([ia.index(c) for c in oa]).contiguous(stream)
+        B2 = B.transpose([ib.index(c) for c in ob]).contiguous(stream)
+        return contract(f"{''.join(oa)},{''.join(ob)}->{co}", A2, B2, out, alpha, accumulate, k_scale,
+                        stream, split_k, _depth=1)
+
+    d = nat.GemmDesc()
+    d.batch, (d.a_b, d.b_b, d.c_b) = mb[0], mb[1]
+    d.M, (d.a_m, d.c_m) = mm[0], mm[1]
+    d.N, (d.b_n, d.c_n) = mn[0], mn[1]
+    d.Ko, d.a_ko, d.b_ko, d.Ki, d.a_ki, d.b_ki = kplan
+    d.alpha = float(alpha)
+    d.accumulate = 1 if accumulate else 0
+    d.split_k = int(split_k)
+    ks = None
+    if k_scale is not None:
+        if not k_scale.is_contiguous() or k_scale.size != d.Ko * d.Ki:
+            raise ValueError("k_scale must be a contiguous vector over the contracted index")
+        ks = ctypes.c_void_p(k_scale.ptr)
+    nat.call("ttsk_gemm", ctypes.byref(d), ctypes.c_void_p(A.ptr), ctypes.c_void_p(B.ptr),
+             ctypes.c_void_p(out.ptr), ks, stream)
+    return out
+
+
+def axpby(y: DevArray, x: DevArray, a: float = 1.0, b: float = 1.0, stream=0):
+    """y <- a*x + b*y (contiguous, same shape)."""
+    if y.shape != x.shape:
+        raise ValueError("axpby: shape mismatch")
+    x = x.contiguous(stream)
+    if not y.is_contiguous():
+        raise ValueError("axpby: destination must be contiguous")
+    if y.size:
+        nat.call("ttsk_axpby", ctypes.c_void_p(y.ptr), ctypes.c_void_p(x.ptr), float(a), float(b),
+                 ctypes.c_size_t(y.size), stream)
+    return y

@@ -1,0 +1,207 @@
+"""Generic sketch driver: left/right partial contractions, Omega_mu, Psi_mu.
+
+Device counterpart of the reference's ``tt_sketch/sketch_dispatch.py``: the same dispatch
+tables keyed by tensor type (:51-82), TensorSum fan-out (:85-147), ``orth_step`` (:160-174),
+``OrthogTTDRM`` (:177-193) and ``general_sketch`` (:202-275).  Partial contractions and the
+sketch stay in HBM (DevArray) from the first DRM step to the last Psi; they are copied to
+the host once, when the ``SketchContainer`` is built.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from functools import partial
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import _native as nat
+from .device import DevArray, as_dev, axpby, contract
+from .drm import TensorTrainDRM
+from .drm_base import DRM
+from .sketch_container import SketchContainer
+from .sketching_methods.abstract_methods import (CansketchCP, CansketchDense, CansketchSparse,
+                                                 CansketchTT, CanSketchTucker)
+from .sketching_methods.cp_sketch import sketch_omega_cp, sketch_psi_cp
+from .sketching_methods.dense_sketch import sketch_omega_dense, sketch_psi_dense
+from .sketching_methods.sparse_sketch import sketch_omega_sparse, sketch_psi_sparse
+from .sketching_methods.tensor_train_sketch import sketch_omega_tt, sketch_psi_tt
+from .sketching_methods.tucker_sketch import sketch_omega_tucker, sketch_psi_tucker
+from .tensor import (CPTensor, DenseTensor, SparseTensor, Tensor, TensorSum, TensorTrain,
+                     TuckerTensor)
+from .utils import pinv_dev
+
+ABSTRACT_TENSOR_SKETCH_DISPATCH = {
+    SparseTensor: CansketchSparse, TensorTrain: CansketchTT, DenseTensor: CansketchDense,
+    CPTensor: CansketchCP, TuckerTensor: CanSketchTucker,
+}
+DRM_SKETCH_METHOD_DISPATCH = {
+    SparseTensor: "sketch_sparse", TensorTrain: "sketch_tt", DenseTensor: "sketch_dense",
+    CPTensor: "sketch_cp", TuckerTensor: "sketch_tucker",
+}
+OMEGA_METHODS = {
+    SparseTensor: sketch_omega_sparse, TensorTrain: sketch_omega_tt, DenseTensor: sketch_omega_dense,
+    CPTensor: sketch_omega_cp, TuckerTensor: sketch_omega_tucker,
+}
+PSI_METHODS = {
+    SparseTensor: sketch_psi_sparse, TensorTrain: sketch_psi_tt, DenseTensor: sketch_psi_dense,
+    CPTensor: sketch_psi_cp, TuckerTensor: sketch_psi_tucker,
+}
+
+
+def _accumulate(acc: Optional[DevArray], term, shape) -> DevArray:
+    term = as_dev(term)
+    if tuple(term.shape) != tuple(shape):
+        raise ValueError(f"summand sketch has shape {term.shape}, expected {tuple(shape)}")
+    if acc is None:
+        return term.copy() if not term.is_contiguous() or term.offset else term
+    return axpby(acc, term, 1.0, 1.0)
+
+
+def sketch_omega_sum(left_sketch_array, right_sketch_array, *, tensor: TensorSum, omega_shape,
+                     **kwargs) -> DevArray:
+    """Omega of a sum = sum of the summands' Omegas (reference :85-105)."""
+    acc = None
+    for summand, l, r in zip(tensor.tensors, left_sketch_array, right_sketch_array):
+        acc = _accumulate(acc, OMEGA_METHODS[type(summand)](
+            l, r, tensor=summand, omega_shape=omega_shape, **kwargs), omega_shape)
+    return DevArray.zeros(omega_shape) if acc is None else acc
+
+
+def sketch_psi_sum(left_sketch_array, right_sketch_array, *, tensor: TensorSum, psi_shape,
+                   **kwargs) -> DevArray:
+    """Psi of a sum (reference :111-136); either side may be None at the ends."""
+    k = tensor.num_summands
+    lefts = (None,) * k if left_sketch_array is None else left_sketch_array
+    rights = (None,) * k if right_sketch_array is None else right_sketch_array
+    acc = None
+    for summand, l, r in zip(tensor.tensors, lefts, rights):
+        acc = _accumulate(acc, PSI_METHODS[type(summand)](
+            l, r, tensor=summand, psi_shape=psi_shape, **kwargs), psi_shape)
+    return DevArray.zeros(psi_shape) if acc is None else acc
+
+
+OMEGA_METHODS[TensorSum] = sketch_omega_sum
+PSI_METHODS[TensorSum] = sketch_psi_sum
+
+
+def sum_sketch(tensor: TensorSum, *, drm: DRM):
+    """Per mode, the tuple of the summands' partial contractions (reference :142-147)."""
+    gens = [get_sketch_method(t, drm)(t) for t in tensor.tensors]
+    for _ in range(len(tensor.shape) - 1):
+        yield tuple(next(g) for g in gens)
+
+
+def get_sketch_method(tensor: Tensor, drm: DRM) -> Callable:
+    """``drm.sketch_<kind>`` for the tensor's type (reference :150-157)."""
+    name = DRM_SKETCH_METHOD_DISPATCH.get(type(tensor))
+    if name is not None:
+        if not hasattr(drm, name):
+            raise ValueError(f"DRM of type {type(drm)} can't sketch {type(tensor)}")
+        return getattr(drm, name)
+    if isinstance(tensor, TensorSum):
+        return partial(sum_sketch, drm=drm)
+    raise ValueError(f"DRM of type {type(drm)} can't sketch {type(tensor)}")
+
+
+def orth_step(Psi, Omega=None) -> DevArray:
+    """Psi <- Q of thin QR(Psi_mat pinv(Omega)) (reference :160-174), all on the device."""
+    P = as_dev(Psi).contiguous()
+    r1, n, r2 = P.shape
+    M = P.reshape(r1 * n, r2)
+    if Omega is not None:
+        M = contract("ij,jk->ik", M, pinv_dev(Omega))
+    elif M is P or M.buf is P.buf:
+        M = M.copy()                       # QR works in place; keep the caller's Psi intact
+    m, k = M.shape
+    if m < k:
+        raise ValueError(f"cannot orthogonalise a {m} x {k} unfolding: trim the sketch ranks")
+    nat.call("ttsk_qr_thin", ctypes.c_void_p(M.ptr), m, k, 0)
+    return M.reshape(r1, n, k)
+
+
+class OrthogTTDRM:
+    """Left 'DRM' whose cores are the already orthogonalised Psi cores (reference :177-193)."""
+
+    def __init__(self, rank, tensor):
+        self.rank = rank
+        self.drm = TensorTrainDRM(rank, tensor.shape, transpose=False, cores=[])
+        self.generator = None
+        self.tensor = tensor
+        self.sketch_method = get_sketch_method(tensor, self.drm)
+
+    def add_core(self, core):
+        self.drm.cores.append(core)
+        if self.generator is None:
+            self.generator = self.sketch_method(self.tensor)
+
+    def __next__(self):
+        return next(self.generator)
+
+
+class SketchMethod(enum.Enum):
+    streaming = "streaming"
+    orthogonal = "orthogonal"
+    hmt = "hmt"
+
+
+def general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
+                          method: SketchMethod) -> Tuple[List[DevArray], List[DevArray]]:
+    """The sketch as device arrays ``(Psi_cores, Omega_mats)`` (reference :202-275)."""
+    d = len(tensor.shape)
+    tensor.prepare_device()
+    if method != SketchMethod.hmt:
+        if left_drm is None:
+            raise ValueError(f"left_drm must be provided for method '{method}'")
+        left_contractions = list(get_sketch_method(tensor, left_drm)(tensor))
+    right_contractions = list(get_sketch_method(tensor, right_drm)(tensor))
+    if left_drm is None:
+        left_drm = right_drm.T          # shape information only (HMT)
+    left_rank = tuple(left_drm.rank)
+    right_rank = tuple(right_drm.rank[::-1])
+
+    Omega_mats: List[DevArray] = []
+    if method != SketchMethod.hmt:
+        omega_method = OMEGA_METHODS[type(tensor)]
+        for mu in range(d - 1):
+            Omega_mats.append(omega_method(left_contractions[mu], right_contractions[mu], tensor=tensor,
+                                           mu=mu, omega_shape=(left_rank[mu], right_rank[mu])))
+
+    orthogonalise = method in (SketchMethod.hmt, SketchMethod.orthogonal)
+    if orthogonalise:
+        left_psi_drm = OrthogTTDRM(left_rank, tensor)
+
+    Psi_cores: List[DevArray] = []
+    psi_method = PSI_METHODS[type(tensor)]
+    for mu in range(d):
+        if mu == 0:
+            left_sketch, r1 = None, 1
+        else:
+            if orthogonalise:
+                left_psi_drm.add_core(Psi_cores[-1])
+                left_sketch = next(left_psi_drm)
+            else:
+                left_sketch = left_contractions[mu - 1]
+            r1 = left_rank[mu - 1]
+        if mu < d - 1:
+            right_sketch, r2 = right_contractions[mu], right_rank[mu]
+        else:
+            right_sketch, r2 = None, 1
+        Psi = psi_method(left_sketch, right_sketch, tensor=tensor, mu=mu,
+                         psi_shape=(r1, tensor.shape[mu], r2))
+        if mu < d - 1:
+            if method == SketchMethod.orthogonal:
+                Psi = orth_step(Psi, Omega_mats[mu])
+            elif method == SketchMethod.hmt:
+                Psi = orth_step(Psi, None)
+        Psi_cores.append(as_dev(Psi))
+    return Psi_cores, Omega_mats
+
+
+def general_sketch(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
+                   method: SketchMethod) -> SketchContainer:
+    """Sketch on the device, result copied to a host ``SketchContainer``."""
+    from . import tt_fused
+    fused = tt_fused.try_stream_sketch(tensor, left_drm, right_drm, method)
+    Psi, Omega = fused if fused is not None else general_sketch_device(tensor, left_drm, right_drm, method)
+    return SketchContainer(Psi, Omega)

@@ -1,0 +1,119 @@
+"""Host-side rank logic and the pseudo-inverse products of the sketch path.
+
+Counterpart of the on-path parts of the reference's ``tt_sketch/utils.py``:
+``process_tt_rank`` / ``trim_ranks`` (:121-175, host integer logic),
+``matricize`` / ``dematricize`` (:63-95), ``right_mul_pinv`` / ``left_mul_pinv``
+(:98-109, here: device Jacobi-SVD pinv + MFMA GEMM) and ``random_normal``
+(:223-227, here: the device counter-based generator).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Generator, List, Sequence, Tuple, Union
+
+import numpy as np
+import numpy.typing as npt
+
+from . import _native as nat
+from .device import DevArray, as_dev, contract
+
+ArrayList = List[npt.NDArray[np.float64]]
+ArrayGenerator = Generator[npt.NDArray[np.float64], None, None]
+TTRank = Union[int, Tuple[int, ...]]
+
+
+def trim_ranks(dims: Tuple[int, ...], ranks: Tuple[int, ...]) -> Tuple[int, ...]:
+    """Largest TT ranks not exceeding ``ranks`` that a tensor of shape ``dims`` can
+    attain (reference utils.py:121-156): bound every bond by the row/column count of
+    its unfolding, then relax neighbouring bonds until r_{k+1} <= r_k * n_k and
+    r_k <= n_k * r_{k+1} hold everywhere (at most 100 sweeps, as the reference)."""
+    d = len(dims)
+    left = np.cumprod([int(n) for n in dims], dtype=object)
+    right = np.cumprod([int(n) for n in dims[::-1]], dtype=object)[::-1]
+    r = [1] + [min(int(ranks[k]), int(left[k]), int(right[k + 1])) for k in range(d - 1)] + [1]
+    for _ in range(100):
+        dirty = False
+        for k, n in enumerate(dims):
+            if r[k + 1] > r[k] * n:
+                r[k + 1] = r[k] * n
+                dirty = True
+            if r[k] > n * r[k + 1]:
+                r[k] = n * r[k + 1]
+                dirty = True
+        if not dirty:
+            break
+    return tuple(int(x) for x in r[1:-1])
+
+
+def process_tt_rank(rank: TTRank, shape: Tuple[int, ...], trim: bool) -> Tuple[int, ...]:
+    """int -> constant tuple, length check (ValueError), optional trimming
+    (reference utils.py:159-175)."""
+    try:
+        out = tuple(rank)  # type: ignore[arg-type]
+    except TypeError:
+        out = (rank,) * (len(shape) - 1)  # type: ignore[assignment]
+    if len(out) != len(shape) - 1:
+        raise ValueError(f"TT-rank {out} doesn't have right number of elements")
+    return trim_ranks(shape, out) if trim else out
+
+
+def matricize(A: npt.NDArray, mode: Union[int, Sequence[int]], mat_shape: bool = False):
+    """Bring ``mode`` to the front and flatten the rest (reference utils.py:63-83)."""
+    lead = (mode,) if isinstance(mode, (int, np.integer)) else tuple(mode)
+    rest = tuple(a for a in range(A.ndim) if a not in lead)
+    B = np.transpose(A, lead + rest)
+    head = B.shape[:len(lead)]
+    if mat_shape:
+        head = (int(np.prod(head, dtype=np.int64)),)
+    return B.reshape(head + (int(np.prod(B.shape[len(lead):], dtype=np.int64)),))
+
+
+def dematricize(A, mode, shape):
+    """Inverse of ``matricize(A, mode)`` for an integer mode (reference utils.py:86-95)."""
+    rest = [n for a, n in enumerate(shape) if a != mode]
+    B = A.reshape([A.shape[0]] + rest)
+    axes = list(range(1, len(shape)))
+    axes.insert(mode, 0)
+    return np.transpose(B, axes)
+
+
+def pinv_dev(Omega, rcond=None, stream=0) -> DevArray:
+    """pinv(Omega) on the device with LAPACK gelsd's truncation (sigma <= rcond*sigma_max
+    dropped, rcond = eps when None) -- the factorisation behind utils.py:98-109."""
+    Om = as_dev(Omega, stream).contiguous(stream)
+    l, r = Om.shape
+    P = DevArray.empty((r, l))
+    nat.call("ttsk_pinv", ctypes.c_void_p(Om.ptr), l, r, -1.0 if rcond is None else float(rcond),
+             ctypes.c_void_p(P.ptr), None, stream)
+    return P
+
+
+def _like_input(result: DevArray, *inputs):
+    return result if any(isinstance(x, DevArray) for x in inputs) else result.get()
+
+
+def right_mul_pinv(A, B, cond=None):
+    """``A @ pinv(B)`` (reference utils.py:98-102)."""
+    out = contract("ij,jk->ik", as_dev(A), pinv_dev(B, cond))
+    return _like_input(out, A, B)
+
+
+def left_mul_pinv(A, B, cond=None):
+    """``pinv(A) @ B`` (reference utils.py:105-109)."""
+    out = contract("ij,jk->ik", pinv_dev(A, cond), as_dev(B))
+    return _like_input(out, A, B)
+
+
+def random_normal_dev(shape, seed=None, scale: float = 1.0, stream=0) -> DevArray:
+    """N(0, scale^2) array generated on the device (hash -> ndtri, keyed by seed and
+    element index).  Stands in for utils.py:178-227, whose stream is host dependent."""
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    out = DevArray.empty(shape)
+    nat.call("ttsk_fill_normal", ctypes.c_void_p(out.ptr), ctypes.c_size_t(out.size),
+             ctypes.c_uint64(int(seed) % 2**64), float(scale), stream)
+    return out
+
+
+def random_normal(shape, seed=None) -> npt.NDArray[np.float64]:
+    return random_normal_dev(shape, seed).get()
