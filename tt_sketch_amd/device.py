@@ -348,9 +348,23 @@ def contract(spec: str, A: DevArray, B: DevArray, out: Optional[DevArray] = None
     if extra:
         raise ValueError(f"contract {spec}: index '{extra[0]}' is summed in one operand only")
 
-    mb = _merge(batch, size, sa, sb, sc)
-    mm = _merge(Mg, size, sa, sc)
-    mn = _merge(Ng, size, sb, sc)
+    # Letters of the M (or N) group that do not merge with the rest can ride in the batch
+    # dimension with stride 0 on the operand that lacks them (a batched product).
+    sa0 = {c: sa.get(c, 0) for c in size}
+    sb0 = {c: sb.get(c, 0) for c in size}
+    mb = mm = mn = None
+    for tm in range(len(Mg) + 1):
+        for tn in range(len(Ng) + 1):
+            if tm and tn:
+                continue
+            bgroup = [c for c in co if c in batch or c in Mg[:tm] or c in Ng[:tn]]
+            mb = _merge(bgroup, size, sa0, sb0, sc)
+            mm = _merge(Mg[tm:], size, sa, sc)
+            mn = _merge(Ng[tn:], size, sb, sc)
+            if mb is not None and mm is not None and mn is not None:
+                break
+        if mb is not None and mm is not None and mn is not None:
+            break
     # K: try single merged dim (any order), else two dims
     Kn = [c for c in Kg if size[c] != 1]
     kplan = None
