@@ -206,8 +206,22 @@ def sketch_fixture():
             tensors.append(t)
             infos.append(info)
         tensor = tensors[0] if len(tensors) == 1 else TensorSum(tensors)
-        ldrm, linfo = make_drm(ldk, lrank, shape, False, rng, seed=11)
-        rdrm, rinfo = make_drm(rdk, rrank, shape, True, rng, seed=23)
+        # Inputs that are not exactly low rank only pin a well-defined answer if every Omega and
+        # every Psi unfolding is well conditioned (a 3 x 5 sign matrix is singular one time in
+        # five); walk the DRM seeds until the reference's own sketch is.
+        generic = any(k in ("sparse", "dense") for k in kinds)
+        for bump in range(50):
+            ldrm, linfo = make_drm(ldk, lrank, shape, False, rng, seed=11 + bump)
+            rdrm, rinfo = make_drm(rdk, rrank, shape, True, rng, seed=23 + bump)
+            if not generic:
+                break
+            sk = general_sketch(tensor, ldrm, rdrm, SketchMethod.streaming)
+            mats = list(sk.Omega_mats) + [P.reshape(-1, P.shape[2]) for P in sk.Psi_cores[:-1]]
+            sv = [np.linalg.svd(M, compute_uv=False) for M in mats]
+            if min(x[-1] / x[0] for x in sv) > 1e-4:
+                break
+        else:
+            raise RuntimeError(f"no well conditioned seed for {name}")
         for i, info in enumerate(infos):
             put(out, f"{name}/tensor{i}", info)
         put(out, f"{name}/left_drm", linfo)

@@ -11,6 +11,7 @@ namespace ttsk {
 void set_error(const char *fmt, ...);
 hipStream_t stream_of(int s);   // nullptr + error set if invalid / not initialised
 int ensure_init();
+void *scratch(int stream, size_t bytes);  // grow-only per-stream arena; nullptr + error on failure
 
 #define TTSK_HIP(call)                                                          \
     do {                                                                        \

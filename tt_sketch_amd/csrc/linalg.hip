@@ -7,6 +7,7 @@
 //                (sketch_dispatch.py:172), row blocks spread over the whole chip, two
 //                launches per column, LAPACK dlarfg sign convention.
 #include <cfloat>
+#include <cmath>
 #include "common.h"
 
 namespace ttsk {
@@ -124,26 +125,39 @@ __device__ __forceinline__ Refl make_refl(double alpha, double xnorm2)
 
 constexpr int QR_ROWS = 128;  // rows per workgroup
 
-// tail2[j] = sum_{i>j} A[i][j]^2
-__global__ void qr_tail_norm_kernel(const double *A, int64_t m, int64_t n, int64_t j, double *tail2)
+// All cross-workgroup reductions of the QR go through per-workgroup partial slots that the
+// NEXT launch sums in a fixed order: no atomics, bit-reproducible results.
+//   tpart[b]        partial of the tail norm^2 of the current pivot column (nb_t slots)
+//   wpart[b*n + k]  partial of w[k] = sum_i v_i M[i][k]                     (nb_w slots)
+__device__ __forceinline__ double sum_slots(const double *p, int nslots, int stride)
 {
-    double acc = 0;
-    for (int64_t i = j + 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        double x = A[i * n + j];
-        acc = fma(x, x, acc);
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(&tail2[j], acc);
+    double s = 0;
+    for (int b = 0; b < nslots; ++b) s += p[(size_t)b * stride];
+    return s;
 }
 
-// w[k] += sum_{i in block, i>=j} v_i * M[i][k], k in [k0, n); v from column j of A.
-__global__ __launch_bounds__(256) void qr_w_kernel(const double *__restrict__ A, const double *__restrict__ M,
-                                                   int64_t m, int64_t n, int64_t j, int64_t k0,
-                                                   const double *__restrict__ tail2, double *__restrict__ w)
+// tpart[b] = sum_{i in block b, i>j} A[i][j]^2 ; block b covers rows j + 128 b ...
+__global__ __launch_bounds__(256) void qr_tail_norm_kernel(const double *A, int64_t m, int64_t n, int64_t j,
+                                                           double *tpart)
 {
-    const Refl h = make_refl(A[j * n + j], tail2[j]);
-    if (h.tau == 0.0) return;
+    const int64_t r0 = j + (int64_t)blockIdx.x * QR_ROWS;
+    const int64_t r1 = r0 + QR_ROWS < m ? r0 + QR_ROWS : m;
+    __shared__ double red[4];
+    double acc = 0;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x)
+        if (i > j) { double x = A[i * n + j]; acc = fma(x, x, acc); }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tpart[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// wpart[b][k] = sum_{i in block b} v_i * M[i][k], k in [k0, n); v from column j of A.
+__global__ __launch_bounds__(256) void qr_w_kernel(const double *A, const double *M, int64_t m, int64_t n,
+                                                   int64_t j, int64_t k0, const double *tpart, int nb_t,
+                                                   double *wpart)
+{
+    const Refl h = make_refl(A[j * n + j], sum_slots(tpart, nb_t, 1));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r0 = j + (int64_t)blockIdx.x * QR_ROWS;
     const int64_t r1 = r0 + QR_ROWS < m ? r0 + QR_ROWS : m;
@@ -151,47 +165,47 @@ __global__ __launch_bounds__(256) void qr_w_kernel(const double *__restrict__ A,
     for (int64_t kb = k0; kb < n; kb += 64) {
         const int64_t k = kb + lane;
         double acc = 0;
-        if (k < n)
+        if (k < n && h.tau != 0.0)
             for (int64_t i = r0 + wave; i < r1; i += 4) {
                 double v = (i == j) ? 1.0 : A[i * n + j] * h.scale;
                 acc = fma(v, M[i * n + k], acc);
             }
         red[wave][lane] = acc;
         __syncthreads();
-        if (wave == 0 && k < n) {
-            double s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-            if (s != 0.0) unsafeAtomicAdd(&w[k], s);
-        }
+        if (wave == 0 && k < n)
+            wpart[(size_t)blockIdx.x * n + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
         __syncthreads();
     }
 }
 
-// M[i][k] -= tau * v_i * w[k] for i>=j, k in [k0,n); optionally accumulate the tail norm of
-// column j+1 of M (rows > j+1) for the next reflector.
-__global__ __launch_bounds__(256) void qr_update_kernel(const double *__restrict__ A, double *__restrict__ M,
-                                                        int64_t m, int64_t n, int64_t j, int64_t k0,
-                                                        const double *__restrict__ tail2,
-                                                        const double *__restrict__ w, double *next_tail2)
+// M[i][k] -= tau * v_i * w[k] for i>=j, k in [k0,n); optionally the tail norm partials of
+// column j+1 of M (rows > j+1) for the next reflector go to next_tpart[b].
+__global__ __launch_bounds__(256) void qr_update_kernel(const double *A, double *M, int64_t m, int64_t n,
+                                                        int64_t j, int64_t k0, const double *tpart, int nb_t,
+                                                        const double *wpart, int nb_w, double *next_tpart)
 {
-    const Refl h = make_refl(A[j * n + j], tail2[j]);
+    const Refl h = make_refl(A[j * n + j], sum_slots(tpart, nb_t, 1));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r0 = j + (int64_t)blockIdx.x * QR_ROWS;
     const int64_t r1 = r0 + QR_ROWS < m ? r0 + QR_ROWS : m;
+    __shared__ double red[4];
     double nacc = 0;
     for (int64_t kb = k0; kb < n; kb += 64) {
         const int64_t k = kb + lane;
         if (k >= n) continue;
-        const double tw = h.tau * w[k];
+        const double tw = h.tau * sum_slots(wpart + k, nb_w, (int)n);
         for (int64_t i = r0 + wave; i < r1; i += 4) {
             double v = (i == j) ? 1.0 : A[i * n + j] * h.scale;
             double x = M[i * n + k];
             if (h.tau != 0.0) { x = fma(-tw, v, x); M[i * n + k] = x; }
-            if (next_tail2 && k == j + 1 && i > j + 1) nacc = fma(x, x, nacc);
+            if (next_tpart && k == j + 1 && i > j + 1) nacc = fma(x, x, nacc);
         }
     }
-    if (next_tail2) {
+    if (next_tpart) {
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_xor(nacc, o);
-        if (lane == 0 && nacc != 0.0) unsafeAtomicAdd(&next_tail2[j + 1], nacc);
+        if (lane == 0) red[wave] = nacc;
+        __syncthreads();
+        if (threadIdx.x == 0) next_tpart[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -218,9 +232,17 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     const int64_t mW = transposed ? r : l, nW = transposed ? l : r;
     TTSK_ARG(nW <= 1024, "ttsk_pinv: min(l, r) = %lld > 1024 unsupported", (long long)nW);
     if (rcond < 0) rcond = DBL_EPSILON;
-    double *ws = nullptr;
+    // Rank-decision floor: one-sided Jacobi returns the rounding noise of a numerically rank
+    // deficient Omega as singular values of size ~eps*||Omega||; gelsd's eps*sigma_max rule then
+    // becomes a coin flip and a kept noise direction is amplified by 1/sigma^2.  Anything within
+    // 16*sqrt(max(l,r)) of that noise level is treated as zero (documented in DESIGN.md).
+    {
+        double floor_ = 16.0 * DBL_EPSILON * sqrt((double)(l > r ? l : r));
+        if (rcond < floor_) rcond = floor_;
+    }
     const size_t ws_elems = (size_t)(mW * nW + nW * nW) + 1;
-    TTSK_HIP(hipMallocAsync((void **)&ws, ws_elems * 8, st));
+    double *ws = (double *)scratch(stream, ws_elems * 8);
+    if (!ws) return TTSK_ERR_HIP;
     int *drank = (int *)(ws + mW * nW + nW * nW);
     hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_omega, l, r, transposed, ws,
                        ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr);
@@ -229,7 +251,6 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
         e = hipMemcpyAsync(host_rank, drank, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    (void)hipFreeAsync(ws, st);
     TTSK_HIP(e);
     return TTSK_OK;
 }
@@ -240,36 +261,34 @@ int ttsk_qr_thin(double *A, int64_t m, int64_t n, int stream)
     TTSK_ARG(A, "ttsk_qr_thin: NULL argument");
     TTSK_ARG(m >= n && n >= 1, "ttsk_qr_thin: need m >= n >= 1, got (%lld, %lld)", (long long)m,
              (long long)n);
-    // scratch: tail2[n+1], w_fact[n*n], w_q[n*n], Q[m*n]
-    double *ws = nullptr;
-    const size_t small = (size_t)(n + 1) + 2 * (size_t)n * n;
-    TTSK_HIP(hipMallocAsync((void **)&ws, (small + (size_t)m * n) * 8, st));
-    hipError_t e = hipMemsetAsync(ws, 0, small * 8, st);
-    double *tail2 = ws, *wf = ws + n + 1, *wq = wf + n * n, *Q = ws + small;
-    if (e == hipSuccess) {
-        unsigned nb = (unsigned)cdiv(m, 256 * 8);
-        hipLaunchKernelGGL(qr_tail_norm_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, A, m, n, (int64_t)0, tail2);
-        // factorisation: reflector j from column j, applied to columns j+1..n-1
-        for (int64_t j = 0; j < n && j < m; ++j) {
-            if (j + 1 >= n) break;  // last column: reflector only (its tail norm is already known)
-            unsigned blocks = (unsigned)cdiv(m - j, QR_ROWS);
-            hipLaunchKernelGGL(qr_w_kernel, dim3(blocks), dim3(256), 0, st, A, A, m, n, j, j + 1, tail2,
-                               wf + j * n);
-            hipLaunchKernelGGL(qr_update_kernel, dim3(blocks), dim3(256), 0, st, A, A, m, n, j, j + 1, tail2,
-                               wf + j * n, tail2);
-        }
-        // Q = H_0 H_1 ... H_{n-1} [I; 0]
-        hipLaunchKernelGGL(eye_kernel, dim3(1024), dim3(256), 0, st, Q, m, n);
-        for (int64_t j = n - 1; j >= 0; --j) {
-            unsigned blocks = (unsigned)cdiv(m - j, QR_ROWS);
-            hipLaunchKernelGGL(qr_w_kernel, dim3(blocks), dim3(256), 0, st, A, Q, m, n, j, j, tail2, wq + j * n);
-            hipLaunchKernelGGL(qr_update_kernel, dim3(blocks), dim3(256), 0, st, A, Q, m, n, j, j, tail2,
-                               wq + j * n, (double *)nullptr);
-        }
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(A, Q, (size_t)m * n * 8, hipMemcpyDeviceToDevice, st);
+    // scratch: tpart[n][nb] (tail-norm partials per pivot column), wpart[nb][n], Q[m*n]
+    const int64_t nb = cdiv(m, QR_ROWS);
+    const size_t small = (size_t)n * nb + (size_t)nb * n;
+    double *ws = (double *)scratch(stream, (small + (size_t)m * n) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *tpart = ws, *wpart = ws + (size_t)n * nb, *Q = ws + small;
+    auto blocks_at = [&](int64_t j) { return (int)cdiv(m - j, QR_ROWS); };
+    hipLaunchKernelGGL(qr_tail_norm_kernel, dim3(blocks_at(0)), dim3(256), 0, st, A, m, n, (int64_t)0, tpart);
+    // factorisation: reflector j from column j applied to columns j+1..n-1; the update of
+    // column j also leaves the tail-norm partials of column j+1 in tpart[j+1][*]
+    for (int64_t j = 0; j + 1 < n; ++j) {
+        const int nbj = blocks_at(j);
+        hipLaunchKernelGGL(qr_w_kernel, dim3(nbj), dim3(256), 0, st, A, A, m, n, j, j + 1, tpart + j * nb,
+                           blocks_at(j > 0 ? j - 1 : 0), wpart);
+        hipLaunchKernelGGL(qr_update_kernel, dim3(nbj), dim3(256), 0, st, A, A, m, n, j, j + 1,
+                           tpart + j * nb, blocks_at(j > 0 ? j - 1 : 0), wpart, nbj, tpart + (j + 1) * nb);
     }
-    (void)hipFreeAsync(ws, st);
+    // Q = H_0 H_1 ... H_{n-1} [I; 0]
+    hipLaunchKernelGGL(eye_kernel, dim3(1024), dim3(256), 0, st, Q, m, n);
+    for (int64_t j = n - 1; j >= 0; --j) {
+        const int nbj = blocks_at(j);
+        const int nbt = blocks_at(j > 0 ? j - 1 : 0);
+        hipLaunchKernelGGL(qr_w_kernel, dim3(nbj), dim3(256), 0, st, A, Q, m, n, j, j, tpart + j * nb, nbt, wpart);
+        hipLaunchKernelGGL(qr_update_kernel, dim3(nbj), dim3(256), 0, st, A, Q, m, n, j, j, tpart + j * nb, nbt,
+                           wpart, nbj, (double *)nullptr);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(A, Q, (size_t)m * n * 8, hipMemcpyDeviceToDevice, st);
     TTSK_HIP(e);
     return TTSK_OK;
 }

@@ -27,6 +27,33 @@ int ensure_init()
     return ttsk_init(0);
 }
 
+// Grow-only scratch arena per library stream.  (hipMallocAsync's stream-ordered pool returned
+// buffers that were corrupted under us on ROCm 7.2 / gfx950 -- measured with the QR kernels --
+// so temporaries come from plain hipMalloc and are reused in stream order.)
+static void *g_scratch[TTSK_NUM_STREAMS];
+static size_t g_scratch_bytes[TTSK_NUM_STREAMS];
+
+void *scratch(int s, size_t bytes)
+{
+    if (ensure_init() != TTSK_OK || s < 0 || s >= TTSK_NUM_STREAMS) return nullptr;
+    if (bytes <= g_scratch_bytes[s]) return g_scratch[s];
+    if (g_scratch[s]) {
+        (void)hipStreamSynchronize(g_streams[s]);
+        (void)hipFree(g_scratch[s]);
+        g_scratch[s] = nullptr;
+        g_scratch_bytes[s] = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&g_scratch[s], want);
+    if (e != hipSuccess) {
+        set_error("scratch allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        g_scratch[s] = nullptr;
+        return nullptr;
+    }
+    g_scratch_bytes[s] = want;
+    return g_scratch[s];
+}
+
 hipStream_t stream_of(int s)
 {
     if (ensure_init() != TTSK_OK) return nullptr;
@@ -76,11 +103,14 @@ int ttsk_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) return TTSK_OK;
     for (int i = 0; i < TTSK_NUM_STREAMS; ++i) {
-        hipStreamSynchronize(g_streams[i]);
-        hipStreamDestroy(g_streams[i]);
-        hipEventDestroy(g_ev_start[i]);
-        hipEventDestroy(g_ev_stop[i]);
-        hipEventDestroy(g_ev_sync[i]);
+        (void)hipStreamSynchronize(g_streams[i]);
+        (void)hipStreamDestroy(g_streams[i]);
+        (void)hipEventDestroy(g_ev_start[i]);
+        (void)hipEventDestroy(g_ev_stop[i]);
+        (void)hipEventDestroy(g_ev_sync[i]);
+        if (g_scratch[i]) (void)hipFree(g_scratch[i]);
+        g_scratch[i] = nullptr;
+        g_scratch_bytes[i] = 0;
     }
     g_init = false;
     g_device = -1;
@@ -204,7 +234,7 @@ int ttsk_graph_end(int stream, void **graph_exec)
     TTSK_HIP(hipStreamEndCapture(st, &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
         return TTSK_ERR_HIP;

@@ -212,19 +212,17 @@ static unsigned grid_for(size_t n, unsigned block = 256, unsigned cap = 16384)
 
 template <typename OUT>
 static int sign_dev(const int64_t *dev_idx, const IndexMap &im, size_t N, int true_rank, int rank_min,
-                    int rank_max, int nnz, uint64_t seed, OUT *dev_out, hipStream_t st)
+                    int rank_max, int nnz, uint64_t seed, OUT *dev_out, hipStream_t st, int stream)
 {
     TTSK_ARG(nnz >= 0 && nnz <= true_rank, "sparse sign: nnz_per_row %d not in [0, %d]", nnz, true_rank);
     TTSK_ARG(0 <= rank_min && rank_min <= rank_max && rank_max <= true_rank,
              "sparse sign: bad rank slice [%d,%d) of %d", rank_min, rank_max, true_rank);
     if (N == 0 || rank_max == rank_min) return TTSK_OK;
-    int8_t *ws = nullptr;
-    TTSK_HIP(hipMallocAsync((void **)&ws, N * (size_t)true_rank, st));
+    int8_t *ws = (int8_t *)scratch(stream, N * (size_t)true_rank);
+    if (!ws) return TTSK_ERR_HIP;
     hipLaunchKernelGGL((sign_kernel<OUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dev_idx, im,
                        N, true_rank, nnz, rank_min, rank_max, seed, ws, dev_out);
-    hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, st);
-    TTSK_HIP(e);
+    TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
 
@@ -278,7 +276,7 @@ int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *
     IndexMap im;
     int rc = make_index_map(shape, m, row_stride, row_order, &im);
     if (rc) return rc;
-    return sign_dev<double>(dev_idx, im, N, true_rank, rank_min, rank_max, nnz_per_row, seed, dev_out, st);
+    return sign_dev<double>(dev_idx, im, N, true_rank, rank_min, rank_max, nnz_per_row, seed, dev_out, st, stream);
 }
 
 static int host_sample(const void *host_idx, const uint64_t *shape, int m, size_t N, int rank_min,
@@ -308,7 +306,7 @@ static int host_sample(const void *host_idx, const uint64_t *shape, int m, size_
             hipLaunchKernelGGL((sample_kernel<1>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, didx,
                                im, N, rank_min, w, seed, (double *)dout);
         else
-            status = sign_dev<int16_t>(didx, im, N, true_rank, rank_min, rank_max, nnz, seed, (int16_t *)dout, st);
+            status = sign_dev<int16_t>(didx, im, N, true_rank, rank_min, rank_max, nnz, seed, (int16_t *)dout, st, 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess && status == TTSK_OK)

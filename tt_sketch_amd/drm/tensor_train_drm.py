@@ -101,7 +101,7 @@ class TensorTrainDRM(CansketchSparse, CansketchTT, CansketchCP, CanSlice, Canske
         order = tensor.dev_row_order
         N = tensor.nnz
         v = None
-        for mu in range(len(self.cores)):
+        for mu, _ in enumerate(self.cores):     # the list may grow while we walk it (OrthogTTDRM)
             D = self._core(mu).contiguous()
             rho, n, rhop = D.shape
             out = DevArray.empty((N, rhop))
