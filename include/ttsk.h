@@ -86,30 +86,38 @@ int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *s
  * (sketch_container.py:61-69) and the TensorSum accumulators (sketch_dispatch.py:93-136) */
 int ttsk_axpby(double *y, const double *x, double a, double b, size_t n, int stream);
 
-/* ---- fused TT-input / TT-DRM kernels --------------------------------------
- * One chain step of TensorTrainDRM.sketch_tt (tensor_train_drm.py:71-88) fused
- * with the interior Psi contraction that shares its first GEMM
- * (tensor_train_sketch.py:28-34):
- *   T[q,k,p']  = sum_p  Lin[p,q] * X[p,k,p']
- *   Lout[p',q'] = sum_{q,k} T[q,k,p'] * D[q,k,q']          (if Lout != NULL)
- *   Psi[q,k,c] = sum_{p'} T[q,k,p'] * R[p',c]             (if Psi != NULL)
- * X is addressed through element strides (x_p, x_k, x_pp) so that the transposed
- * tensor of a right sketch (tensor.py:311-313) needs no copy.  Lin may be NULL for
- * the first mode (s = l = 1, T = X).  Lout accumulates atomically and must be
- * zeroed by the caller (ttsk_memset).  Columns [q_lo, q_hi) of the running
- * contraction are the DRM's rank_min/rank_max slice and are applied by the caller
- * through pointer/ld arithmetic (tensor_train_drm.py:88). */
-typedef struct {
-    int64_t s, n, sp;      /* X is (s, n, sp) through strides */
-    int64_t l, lp;         /* DRM core D is (l, n, lp), contiguous */
-    int64_t r;             /* R is (sp, r) with leading dimension ldr; 0 if no Psi */
-    int64_t x_p, x_k, x_pp;
-    int64_t ldlin, ldlout, ldr;
-    int64_t psi_q, psi_k, psi_c;   /* element strides of Psi[q,k,c] */
-} ttsk_tt_step_desc;
-int ttsk_tt_step(const ttsk_tt_step_desc *desc, const double *Lin, const double *X,
-                 const double *D, const double *R, double *Lout, double *Psi, int stream);
-/* Omega_mu = L_mu^T R_mu (tensor_train_sketch.py:8-11) is a ttsk_gemm. */
+/* ---- TT input x TT DRMs: the whole streaming sketch in one call ---------------
+ * general_sketch(TensorTrain, TensorTrainDRM, TensorTrainDRM, streaming)
+ * (sketch_dispatch.py:202-275) = right chain + left chain of TensorTrainDRM.sketch_tt
+ * (tensor_train_drm.py:71-88, through handle_transpose drm_base.py:122-145 for the right
+ * side, without materialising tensor.T), Omega_mu = L_mu^T R_mu and
+ * Psi_mu = L_{mu-1}^T X_mu R_mu (tensor_train_sketch.py:8-35).  The first GEMM of a left
+ * chain step, T = L_{mu-1}^T X_mu, is shared with Psi_mu.
+ *
+ *   n[d]              mode sizes
+ *   s[d+1]            TT ranks of the input, s[0] = s[d] = 1; X[mu] is (s[mu], n[mu], s[mu+1])
+ *   lt[d]             true ranks of the left DRM, lt[0] = 1; DL[mu] is (lt[mu], n[mu], lt[mu+1]), mu < d-1
+ *   rt[d]             true ranks of the right DRM in ITS walking order (mode d-1 first), rt[0] = 1;
+ *                     DR[j] is (rt[j], n[d-1-j], rt[j+1]), j < d-1
+ *   l_lo/l_hi[d-1]    rank_min / rank_max of the left DRM (slice of the yielded contraction, :88)
+ *   r_lo/r_hi[d-1]    same for the right DRM, in its walking order
+ *   out               packed [Psi_0 .. Psi_{d-1}, Omega_0 .. Omega_{d-2}], Psi_mu (l_{mu-1}, n_mu, r_mu),
+ *                     Omega_mu (l_mu, r_mu) with l, r the sliced ranks in user order -- the buffer that
+ *                     ttsk_comm_allreduce_sum reduces.  accumulate != 0 adds (TensorSum / `stt + X`,
+ *                     sketch_dispatch.py:85-139, sketch.py:292-301).
+ * All pointer arrays are host arrays of device pointers. */
+int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                   const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                   const double *const *X, const double *const *DL, const double *const *DR,
+                   double *out, int accumulate, int stream);
+/* number of doubles ttsk_tt_sketch writes to `out` */
+int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
+                            const int64_t *r_lo, const int64_t *r_hi);
+/* per-kernel device timing of the launches made by ttsk_tt_sketch (bench.py roofline leg):
+ * while enabled every GEMM launch is bracketed by hipEvents on its stream. */
+int ttsk_prof_enable(int on);
+/* class 0: chain GEMM1 (T = L^T X), 1: chain GEMM2 (split-K), 2: Psi GEMM, 3: other */
+int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops);
 
 /* ---- hash sampler (the reference's native module) -------------------------
  * Host-pointer twins of the Cython API (fast_lazy_gaussian.pyx:14,53,156,183);

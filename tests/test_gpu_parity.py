@@ -311,3 +311,28 @@ def test_massive_oversample_and_errors(tsa):
         list(bad.sketch_tt(X))
     with pytest.raises(ValueError):
         tsa.stream_sketch(X, (3, 3, 3), (4, 4, 4), left_drm=tsa.TensorTrainDRM(4, X.shape, False, seed=1))
+
+
+def test_one_call_tt_path_matches_generic_and_oracle(tsa):
+    """ttsk_tt_sketch (one C call) == generator protocol path == oracle, incl. rank slices
+    and TensorSum accumulation."""
+    from tt_sketch_amd import tt_fused
+    from tt_sketch_amd.sketch_dispatch import general_sketch_device
+    from tests.gpu_build import make_drm, make_tensor
+    rng = np.random.default_rng(11)
+    shape, s = (9, 12, 7, 10, 8), (3, 6, 5, 4)
+    lr, rr = (4, 7, 6, 5), (6, 9, 8, 7)
+    terms = [orc.random_tt(shape, s, rng) for _ in range(3)]
+    ld = orc.random_tt_drm(shape, lr, False, rng)
+    rd = orc.random_tt_drm(shape, rr, True, rng)
+    ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)
+    rd.rank_min, rd.rank_max = (0, 3, 1, 2), (5, 8, 9, 6)       # walking order of the right DRM
+    for data in (("tt", terms[0]), ("sum", [("tt", t) for t in terms])):
+        T = make_tensor(*data)
+        L, R = make_drm(ld), make_drm(rd)
+        fused = tt_fused.try_stream_sketch(T, L, R, tsa.SketchMethod.streaming)
+        assert fused is not None
+        gen = general_sketch_device(T, L, R, tsa.SketchMethod.streaming)
+        oP, oO = orc.general_sketch(data[0], data[1], ld, rd, "streaming")
+        for a, b, c in zip(fused[0] + fused[1], gen[0] + gen[1], oP + oO):
+            assert rel(a.get(), c) < TOL and rel(b.get(), c) < TOL

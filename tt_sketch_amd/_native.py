@@ -33,12 +33,6 @@ class GemmDesc(Structure):
         ("alpha", c_double), ("accumulate", c_int), ("split_k", c_int)]
 
 
-class TTStepDesc(Structure):
-    _fields_ = [(n, c_int64) for n in
-                ("s", "n", "sp", "l", "lp", "r", "x_p", "x_k", "x_pp",
-                 "ldlin", "ldlout", "ldr", "psi_q", "psi_k", "psi_c")]
-
-
 _lib = None
 
 
@@ -62,7 +56,9 @@ def _bind(lib):
         "ttsk_gemm": [POINTER(GemmDesc), P, P, P, P, I],
         "ttsk_copy_strided": [P, P, I, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), I],
         "ttsk_axpby": [P, P, c_double, c_double, S, I],
-        "ttsk_tt_step": [POINTER(TTStepDesc), P, P, P, P, P, P, I],
+        "ttsk_tt_sketch": [I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
+        "ttsk_prof_enable": [I],
+        "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
         "ttsk_hash_u64": [P, S],
         "ttsk_inds_to_rand_double": [P, P, I, S, I, I, c_uint64, P],
         "ttsk_inds_to_normal": [P, P, I, S, I, I, c_uint64, P],
@@ -88,6 +84,8 @@ def _bind(lib):
         fn.restype = c_int
     lib.ttsk_last_error.restype = c_char_p
     lib.ttsk_last_error.argtypes = []
+    lib.ttsk_tt_sketch_size.restype = c_int64
+    lib.ttsk_tt_sketch_size.argtypes = [I] + [POINTER(c_int64)] * 5
 
 
 def lib():

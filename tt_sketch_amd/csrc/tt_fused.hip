@@ -1,11 +1,206 @@
-// Fused TT-input / TT-DRM step (placeholder until the LDS-resident kernel lands):
-// reports TTSK_ERR_UNSUPPORTED so that the host composes the step from ttsk_gemm.
+// TT input x TT DRMs: the whole streaming sketch (both chains, Omega, Psi) as one C call.
+// See include/ttsk.h (ttsk_tt_sketch) for the contract and the reference lines it replaces.
+#include <vector>
 #include "common.h"
-using namespace ttsk;
-extern "C" int ttsk_tt_step(const ttsk_tt_step_desc *desc, const double *Lin, const double *X,
-                            const double *D, const double *R, double *Lout, double *Psi, int stream)
+
+namespace ttsk {
+
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static int64_t g_launches[4];
+static double g_ms[4], g_flops[4];
+
+static void prof_flush()
 {
-    (void)desc; (void)Lin; (void)X; (void)D; (void)R; (void)Lout; (void)Psi; (void)stream;
-    set_error("ttsk_tt_step: shape not supported by the fused kernel");
-    return TTSK_ERR_UNSUPPORTED;
+    for (auto &r : g_recs) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_launches[r.cls]++;
+            g_ms[r.cls] += ms;
+            g_flops[r.cls] += r.flops;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
 }
+
+// C[M,N] (+)= A * B with generic strides; thin wrapper that also does the profiling bracket.
+static int gemm(int cls, int64_t M, int64_t N, int64_t Ko, int64_t Ki, const double *A, int64_t a_m,
+                int64_t a_ko, int64_t a_ki, const double *B, int64_t b_ko, int64_t b_ki, int64_t b_n,
+                double *C, int64_t c_m, int64_t c_n, int accumulate, int stream)
+{
+    ttsk_gemm_desc d{};
+    d.batch = 1; d.M = M; d.N = N; d.Ko = Ko; d.Ki = Ki;
+    d.a_m = a_m; d.a_ko = a_ko; d.a_ki = a_ki;
+    d.b_ko = b_ko; d.b_ki = b_ki; d.b_n = b_n;
+    d.c_m = c_m; d.c_n = c_n;
+    d.alpha = 1.0; d.accumulate = accumulate; d.split_k = 0;
+    ProfRec r{};
+    hipStream_t st = stream_of(stream);
+    if (g_prof) {
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+    }
+    int rc = ttsk_gemm(&d, A, B, C, nullptr, stream);
+    if (g_prof) {
+        (void)hipEventRecord(r.b, st);
+        r.cls = cls;
+        r.flops = 2.0 * (double)M * (double)N * (double)(Ko * Ki);
+        g_recs.push_back(r);
+    }
+    return rc;
+}
+
+}  // namespace ttsk
+
+using namespace ttsk;
+
+extern "C" {
+
+int ttsk_prof_enable(int on)
+{
+    if (ensure_init() != TTSK_OK) return TTSK_ERR_HIP;
+    if (!on) prof_flush();
+    else {
+        prof_flush();
+        for (int i = 0; i < 4; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_flops[i] = 0; }
+    }
+    g_prof = on != 0;
+    return TTSK_OK;
+}
+
+int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops)
+{
+    TTSK_ARG(cls >= 0 && cls < 4, "ttsk_prof_read: class %d", cls);
+    prof_flush();
+    if (launches) *launches = g_launches[cls];
+    if (total_ms) *total_ms = g_ms[cls];
+    if (flops) *flops = g_flops[cls];
+    return TTSK_OK;
+}
+
+int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
+                            const int64_t *r_lo, const int64_t *r_hi)
+{
+    int64_t tot = 0;
+    for (int mu = 0; mu < d; ++mu) {
+        int64_t l = mu == 0 ? 1 : l_hi[mu - 1] - l_lo[mu - 1];
+        int64_t r = mu == d - 1 ? 1 : r_hi[d - 2 - mu] - r_lo[d - 2 - mu];
+        tot += l * n[mu] * r;
+    }
+    for (int mu = 0; mu < d - 1; ++mu)
+        tot += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
+    return tot;
+}
+
+int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                   const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                   const double *const *X, const double *const *DL, const double *const *DR, double *out,
+                   int accumulate, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(d >= 2, "ttsk_tt_sketch: need d >= 2, got %d", d);
+    TTSK_ARG(n && s && lt && l_lo && l_hi && rt && r_lo && r_hi && X && DL && DR && out,
+             "ttsk_tt_sketch: NULL argument");
+    TTSK_ARG(s[0] == 1 && s[d] == 1 && lt[0] == 1 && rt[0] == 1, "ttsk_tt_sketch: boundary ranks must be 1");
+    for (int mu = 0; mu < d - 1; ++mu) {
+        TTSK_ARG(0 <= l_lo[mu] && l_lo[mu] <= l_hi[mu] && l_hi[mu] <= lt[mu + 1],
+                 "ttsk_tt_sketch: left rank slice %d out of range", mu);
+        TTSK_ARG(0 <= r_lo[mu] && r_lo[mu] <= r_hi[mu] && r_hi[mu] <= rt[mu + 1],
+                 "ttsk_tt_sketch: right rank slice %d out of range", mu);
+    }
+    // workspace: Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]), T (max over modes)
+    size_t tot = 0, tmax = 0;
+    std::vector<size_t> offL(d - 1), offR(d - 1);
+    for (int mu = 0; mu < d - 1; ++mu) { offL[mu] = tot; tot += (size_t)s[mu + 1] * lt[mu + 1]; }
+    for (int j = 0; j < d - 1; ++j) { offR[j] = tot; tot += (size_t)s[d - 1 - j] * rt[j + 1]; }
+    for (int mu = 1; mu < d; ++mu) {
+        size_t tl = (size_t)lt[mu] * n[mu] * s[mu + 1];              // left step / Psi at mode mu
+        size_t tr = (size_t)rt[d - 1 - mu] * n[mu] * s[mu];          // right step at mode mu (j = d-1-mu)
+        if (mu < d) tmax = tl > tmax ? tl : tmax;
+        if (mu < d - 1) tmax = tr > tmax ? tr : tmax;
+    }
+    double *ws = (double *)scratch(stream, (tot + tmax) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *T = ws + tot;
+    int rc;
+#define CK(x) do { rc = (x); if (rc) return rc; } while (0)
+
+    // ---- right chain: walks modes d-1, d-2, ..., 1 on the transposed tensor (views only).
+    // Xt_j[p,k,p''] = X_mu[p'',k,p], mu = d-1-j.
+    for (int j = 0; j < d - 1; ++j) {
+        const int mu = d - 1 - j;
+        const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
+        double *Rn = ws + offR[j];
+        if (j == 0) {
+            // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
+            CK(gemm(3, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
+        } else {
+            const double *Rc = ws + offR[j - 1];                   // (sp x rho)
+            // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
+            CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
+            // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
+            CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+        }
+    }
+    // ---- left chain fused with Psi and Omega
+    double *psi = out;
+    std::vector<double *> psi_at(d), om_at(d - 1);
+    {
+        double *p = out;
+        for (int mu = 0; mu < d; ++mu) {
+            int64_t l = mu == 0 ? 1 : l_hi[mu - 1] - l_lo[mu - 1];
+            int64_t r = mu == d - 1 ? 1 : r_hi[d - 2 - mu] - r_lo[d - 2 - mu];
+            psi_at[mu] = p;
+            p += l * n[mu] * r;
+        }
+        for (int mu = 0; mu < d - 1; ++mu) {
+            om_at[mu] = p;
+            p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
+        }
+    }
+    (void)psi;
+    for (int mu = 0; mu < d; ++mu) {
+        const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
+        // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
+        const int jr = d - 2 - mu;
+        const double *Rm = mu < d - 1 ? ws + offR[jr] + r_lo[jr] : nullptr;
+        const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
+        if (mu == 0) {
+            // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c]
+            CK(gemm(2, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, stream));
+            // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
+            CK(gemm(3, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, stream));
+        } else {
+            const int64_t lfull = lt[mu], l = l_hi[mu - 1] - l_lo[mu - 1];
+            const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
+            // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
+            CK(gemm(0, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, stream));
+            const double *Ts = T + l_lo[mu - 1] * nn * sp;          // rows of the rank slice
+            if (mu < d - 1) {
+                // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
+                CK(gemm(2, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, stream));
+                // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
+                CK(gemm(1, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1,
+                        ws + offL[mu], lt[mu + 1], 1, 0, stream));
+            } else {
+                // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
+                if (accumulate) CK(ttsk_axpby(psi_at[mu], Ts, 1.0, 1.0, (size_t)(l * nn), stream));
+                else TTSK_HIP(hipMemcpyAsync(psi_at[mu], Ts, (size_t)(l * nn) * 8, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        if (mu < d - 1) {
+            // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]
+            const int64_t l = l_hi[mu] - l_lo[mu];
+            CK(gemm(3, l, r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1, om_at[mu], r, 1,
+                    accumulate, stream));
+        }
+    }
+#undef CK
+    return TTSK_OK;
+}
+
+}  // extern "C"

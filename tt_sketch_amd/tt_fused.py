@@ -1,6 +1,113 @@
-"""Fused fast path for TT / sum-of-TT inputs with TT DRMs (the north-star configuration).
-Placeholder: returns None so that general_sketch composes the path from ttsk_gemm."""
+"""Fast path: TT (or sum-of-TT) input with tensor-train DRMs on both sides, streaming method.
+
+One C call (``ttsk_tt_sketch``) runs both DRM chains, every Omega and every Psi on the device
+and leaves the sketch in ONE packed buffer ``[Psi_0 .. Psi_{d-1}, Omega_0 .. Omega_{d-2}]`` --
+the layout the multi-GPU partial-sketch sum reduces.  Numerically this is the same sequence of
+contractions as ``TensorTrainDRM.sketch_tt`` + ``sketch_omega_tt`` / ``sketch_psi_tt``
+(reference tensor_train_drm.py:71-88, tensor_train_sketch.py:8-35), minus the Python round trips.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native as nat
+from .device import DevArray
+from .drm.tensor_train_drm import TensorTrainDRM
+from .tensor import TensorSum, TensorTrain
+
+_I64 = ctypes.c_int64
 
 
-def try_stream_sketch(tensor, left_drm, right_drm, method):
-    return None
+class TTSketchPlan:
+    """Argument block of ``ttsk_tt_sketch`` for fixed DRMs and a fixed input signature
+    (mode sizes and TT ranks); ``run`` sketches any TT with that signature."""
+
+    def __init__(self, shape, tt_rank, left_drm: TensorTrainDRM, right_drm: TensorTrainDRM):
+        d = len(shape)
+        self.d = d
+        self.shape = tuple(int(x) for x in shape)
+        self.tt_rank = tuple(int(x) for x in tt_rank)
+        arr = lambda v: (_I64 * len(v))(*[int(x) for x in v])
+        self.n = arr(self.shape)
+        self.s = arr((1,) + self.tt_rank + (1,))
+        self.lt = arr((1,) + tuple(left_drm.true_rank))
+        self.rt = arr((1,) + tuple(right_drm.true_rank))
+        self.l_lo, self.l_hi = arr(left_drm.rank_min), arr(left_drm.rank_max)
+        self.r_lo, self.r_hi = arr(right_drm.rank_min), arr(right_drm.rank_max)
+        self._keep = (left_drm.dev_cores(), right_drm.dev_cores())
+        for k, c in enumerate(self._keep[0]):
+            want = (self.lt[k], self.shape[k], self.lt[k + 1])
+            if tuple(c.shape) != want:
+                raise ValueError(f"left DRM core {k} has shape {c.shape}, expected {want}")
+        for k, c in enumerate(self._keep[1]):
+            want = (self.rt[k], self.shape[d - 1 - k], self.rt[k + 1])
+            if tuple(c.shape) != want:
+                raise ValueError(f"right DRM core {k} has shape {c.shape}, expected {want}")
+        P = ctypes.c_void_p
+        self.DL = (P * (d - 1))(*[c.contiguous().ptr for c in self._keep[0]])
+        self.DR = (P * (d - 1))(*[c.contiguous().ptr for c in self._keep[1]])
+        self.left_rank = tuple(left_drm.rank)
+        self.right_rank = tuple(right_drm.rank[::-1])
+        self.size = int(nat.lib().ttsk_tt_sketch_size(d, self.n, self.l_lo, self.l_hi, self.r_lo, self.r_hi))
+
+    def new_buffer(self) -> DevArray:
+        return DevArray.empty((self.size,))
+
+    def core_pointers(self, tt: TensorTrain):
+        cores = tt.dev_cores()
+        if tuple(tt.shape) != self.shape or tuple(tt.rank) != self.tt_rank:
+            raise ValueError(f"TT of shape {tt.shape} / rank {tt.rank} does not fit the plan")
+        keep = [c.contiguous() for c in cores]
+        return (ctypes.c_void_p * self.d)(*[c.ptr for c in keep]), keep
+
+    def run(self, X_ptrs, out: DevArray, accumulate: bool = False, stream: int = 0):
+        nat.call("ttsk_tt_sketch", self.d, self.n, self.s, self.lt, self.l_lo, self.l_hi, self.rt,
+                 self.r_lo, self.r_hi, X_ptrs, self.DL, self.DR, ctypes.c_void_p(out.ptr),
+                 1 if accumulate else 0, stream)
+
+    def views(self, out: DevArray) -> Tuple[List[DevArray], List[DevArray]]:
+        """Psi / Omega arrays as views into the packed buffer."""
+        d, off = self.d, 0
+        lr, rr = (1,) + self.left_rank, self.right_rank + (1,)
+        Psi, Om = [], []
+        for mu in range(d):
+            shp = (lr[mu], self.shape[mu], rr[mu])
+            size = int(np.prod(shp))
+            Psi.append(out[off:off + size].reshape(shp))
+            off += size
+        for mu in range(d - 1):
+            shp = (self.left_rank[mu], self.right_rank[mu])
+            size = shp[0] * shp[1]
+            Om.append(out[off:off + size].reshape(shp))
+            off += size
+        return Psi, Om
+
+
+def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list, list]]:
+    """(Psi, Omega) device arrays through the one-call path, or None if it does not apply."""
+    from .sketch_dispatch import SketchMethod
+    if method != SketchMethod.streaming:
+        return None
+    if type(left_drm) is not TensorTrainDRM or type(right_drm) is not TensorTrainDRM:
+        return None
+    if left_drm.transpose or not right_drm.transpose:
+        return None
+    terms = tensor.tensors if isinstance(tensor, TensorSum) else [tensor]
+    if not terms or not all(type(t) is TensorTrain for t in terms):
+        return None
+    d = len(tensor.shape)
+    if d < 2 or len(left_drm.cores) != d - 1 or len(right_drm.cores) != d - 1:
+        return None
+    if tuple(left_drm.shape) != tuple(tensor.shape) or tuple(right_drm.shape) != tuple(tensor.shape):
+        raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensor.shape}")
+    out = None
+    for k, tt in enumerate(terms):
+        plan = TTSketchPlan(tt.shape, tt.rank, left_drm, right_drm)
+        if out is None:
+            out = plan.new_buffer()
+        ptrs, keep = plan.core_pointers(tt)
+        plan.run(ptrs, out, accumulate=k > 0)
+    return plan.views(out)
