@@ -1,0 +1,241 @@
+"""Benchmark: TT-cores sketched / second (fp64) of stream_sketch on the north-star workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): TensorTrain d=6, n=200, TT-rank 100,
+TensorTrainDRM left rank 50 (r_out), right rank 100, all fp64, synthetic Gaussian cores.  A step
+sketches one such TT per GPU with inputs and DRMs resident in HBM (ttsk_tt_sketch: both chains,
+Omega, Psi).  With N > 1 ranks every rank sketches its own summand and ONE RCCL all-reduce sums
+the packed partial sketches (the sketch of the N-term TensorSum) -- weak scaling, value = cores
+sketched by all ranks per second.
+
+The JSON line also carries
+  roofline      the dominant GEMM class of the pipeline: algorithmic flops / hipEvent time per
+                launch against the fp64 MFMA peak (78.6 TF/s data sheet; probed ceiling reported)
+  cpu_baseline  the CPU oracle (NumPy restatement of the reference, same einsum calls) on the
+                same inputs, on this box's host cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, N_MODE, S_IN, L_RANK, R_RANK = 6, 200, 100, 50, 100
+PEAK_F64_MFMA_TF = 78.6   # AMD MI355X data sheet (fp64 matrix); not listed in MI355X_MICROARCH.md
+
+
+def algorithmic_flops(shape, s, l, r):
+    """cheapest pairwise order of every 3-operand einsum, unfused."""
+    d = len(shape)
+    S = (1,) + tuple(s) + (1,)
+    Lr = (1,) + tuple(l)
+    Rr = tuple(r) + (1,)
+
+    def chain(rk):
+        tot = 2 * shape[0] * S[1] * rk[1]
+        for mu in range(1, d - 1):
+            a, n, b, p, q = S[mu], shape[mu], S[mu + 1], rk[mu], rk[mu + 1]
+            tot += min(2 * a * p * n * b + 2 * p * n * b * q, 2 * a * p * n * q + 2 * a * n * b * q)
+        return tot
+    left = chain(Lr)
+    # right chain walks the transposed tensor
+    St, shp_t, Rt = S[::-1], shape[::-1], (1,) + tuple(r[::-1])
+    right = 2 * shp_t[0] * St[1] * Rt[1]
+    for mu in range(1, d - 1):
+        a, n, b, p, q = St[mu], shp_t[mu], St[mu + 1], Rt[mu], Rt[mu + 1]
+        right += min(2 * a * p * n * b + 2 * p * n * b * q, 2 * a * p * n * q + 2 * a * n * b * q)
+    omega = sum(2 * l[mu] * S[mu + 1] * r[mu] for mu in range(d - 1))
+    psi = 2 * shape[0] * S[1] * Rr[0] + 2 * Lr[d - 1] * S[d - 1] * shape[d - 1]
+    for mu in range(1, d - 1):
+        a, n, b, p, q = S[mu], shape[mu], S[mu + 1], Lr[mu], Rr[mu]
+        psi += min(2 * p * a * n * b + 2 * p * n * b * q, 2 * a * n * b * q + 2 * p * a * n * q)
+    return dict(left=left, right=right, omega=omega, psi=psi, total=left + right + omega + psi)
+
+
+def make_inputs(seed):
+    rng = np.random.default_rng(seed)
+    shape = (N_MODE,) * D
+    S = (1,) + (S_IN,) * (D - 1) + (1,)
+    cores = [rng.standard_normal((S[k], shape[k], S[k + 1])) / np.sqrt(S[k] * shape[k]) for k in range(D)]
+
+    def drm_cores(rank):
+        rk = (1,) + (rank,) * (D - 1)
+        return [rng.standard_normal((rk[k], N_MODE, rk[k + 1])) / np.sqrt(rk[k]) for k in range(D - 1)]
+    return shape, cores, drm_cores(L_RANK), drm_cores(R_RANK)
+
+
+def cpu_baseline(shape, cores, lcores, rcores, budget_s=12.0):
+    """Oracle (port of the reference path, same einsum strings/optimize flags) on host cores."""
+    import __graft_entry__ as ge
+    ge.build_oracle()
+    from oracle import ttsk_oracle as orc
+    ld = orc.TTDrm(lcores, shape, False)
+    rd = orc.TTDrm(rcores, shape, True)
+    orc.general_sketch("tt", cores, ld, rd, "streaming")       # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 40):
+        t0 = time.perf_counter()
+        res = orc.general_sketch("tt", cores, ld, rd, "streaming")
+        times.append(time.perf_counter() - t0)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    best = min(times)
+    return dict(value=D / best, unit="TT-cores/s", cores=int(threads), kind="port",
+                sample=f"{len(times)} sketches of the same d={D} n={N_MODE} s={S_IN} l={L_RANK} r={R_RANK} TT, "
+                       f"DRMs pre-built; best {best * 1e3:.1f} ms, median {np.median(times) * 1e3:.1f} ms",
+                ), res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph (1) or launch eagerly (0)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd import TensorTrain, TensorTrainDRM
+    from tt_sketch_amd.tt_fused import TTSketchPlan
+    nat.call("ttsk_init", local_rank)
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # host-side rendezvous only
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            nat.call("ttsk_comm_unique_id", uid)
+        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, 0)
+        uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.numpy().tobytes()))
+        nat.call("ttsk_comm_init", uid, rank, world)
+
+    shape, cores, lcores, rcores = make_inputs(seed=3 + rank)
+    _, _, lcores, rcores = (shape, cores) + tuple(make_inputs(seed=3)[2:])   # DRMs shared by all ranks
+    tt = TensorTrain(cores)
+    left = TensorTrainDRM(L_RANK, shape, False, seed=1, cores=lcores)
+    right = TensorTrainDRM(R_RANK, shape, True, seed=2, cores=rcores)
+    plan = TTSketchPlan(tt.shape, tt.rank, left, right)
+    out = plan.new_buffer()
+    ptrs, keep = plan.core_pointers(tt)
+
+    def step_eager():
+        plan.run(ptrs, out)
+        if world > 1:
+            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(out.ptr), ctypes.c_size_t(plan.size), 0)
+
+    graph = ctypes.c_void_p()
+    step_eager()
+    nat.call("ttsk_sync", -1)
+    use_graph = bool(args.graph) and world == 1
+    if use_graph:
+        nat.call("ttsk_graph_begin", 0)
+        plan.run(ptrs, out)
+        nat.call("ttsk_graph_end", 0, ctypes.byref(graph))
+
+    def step():
+        if use_graph:
+            nat.call("ttsk_graph_launch", graph, 0)
+        else:
+            step_eager()
+
+    def barrier():
+        nat.call("ttsk_sync", -1)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    result = None
+    if rank == 0:
+        fl = algorithmic_flops(shape, (S_IN,) * (D - 1), (L_RANK,) * (D - 1), (R_RANK,) * (D - 1))
+        # ---- roofline leg: per-launch device time of each GEMM class (hipEvents on the launch stream)
+        nat.call("ttsk_prof_enable", 1)
+        reps = max(5, min(args.steps, 50))
+        for _ in range(reps):
+            plan.run(ptrs, out)
+        nat.call("ttsk_sync", -1)
+        classes = {}
+        names = {0: "chain_gemm1 T=L^T X", 1: "chain_gemm2 split-K", 2: "psi_gemm", 3: "small (Omega, mode 0)"}
+        for c in range(4):
+            n_l, ms, flops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            nat.call("ttsk_prof_read", c, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(flops))
+            if n_l.value:
+                classes[names[c]] = dict(launches_per_sketch=n_l.value / reps, avg_us=1e3 * ms.value / n_l.value,
+                                         tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
+                                         share_ms=ms.value / reps)
+        nat.call("ttsk_prof_enable", 0)
+        dom = max(classes, key=lambda k: classes[k]["share_ms"])
+        probe = ctypes.c_double()
+        nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
+        roofline = dict(bound="mfma", kernel=dom, achieved=classes[dom]["tflops"], peak=PEAK_F64_MFMA_TF,
+                        unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF, traffic=None,
+                        avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value,
+                        classes=classes,
+                        pipeline_tflops=fl["total"] * args.gpus * args.steps / elapsed * 1e-12)
+        cpu = None
+        parity = None
+        if not args.no_cpu:
+            cpu, ref = cpu_baseline(shape, cores, lcores, rcores)
+            if world == 1:
+                got = out.get()
+                want = np.concatenate([a.ravel() for a in ref[0] + ref[1]])
+                parity = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        ms_step = 1e3 * elapsed / args.steps
+        result = dict(metric="TT-cores sketched/sec (fp64), stream_sketch d=6 n=200 r=50",
+                      value=D * args.gpus * args.steps / elapsed, unit="TT-cores/s", n_gpus=args.gpus,
+                      steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
+                      scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                      config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / "
+                                           "right rank 100, streaming sketch (both chains, Omega, Psi), "
+                                           "one TT per GPU per step" +
+                                           ("; partial sketches summed by one RCCL all-reduce" if world > 1 else ""),
+                                  d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
+                                  algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
+                                  sketch_bytes=plan.size * 8),
+                      roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        nat.call("ttsk_comm_destroy")
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

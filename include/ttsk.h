@@ -116,6 +116,10 @@ int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const 
 /* per-kernel device timing of the launches made by ttsk_tt_sketch (bench.py roofline leg):
  * while enabled every GEMM launch is bracketed by hipEvents on its stream. */
 int ttsk_prof_enable(int on);
+/* measured ceiling of v_mfma_f64_16x16x4_f64 on this device (register-resident operands,
+ * 4 independent accumulators per wave, every CU busy): TFLOP/s.  MI355X_MICROARCH.md lists
+ * no fp64 MFMA row, so bench.py states this number next to the 78.6 TF/s data-sheet value. */
+int ttsk_mfma_f64_peak_probe(double *tflops);
 /* class 0: chain GEMM1 (T = L^T X), 1: chain GEMM2 (split-K), 2: Psi GEMM, 3: other */
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops);
 

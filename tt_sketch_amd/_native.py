@@ -58,6 +58,7 @@ def _bind(lib):
         "ttsk_axpby": [P, P, c_double, c_double, S, I],
         "ttsk_tt_sketch": [I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
         "ttsk_prof_enable": [I],
+        "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
         "ttsk_hash_u64": [P, S],
         "ttsk_inds_to_rand_double": [P, P, I, S, I, I, c_uint64, P],

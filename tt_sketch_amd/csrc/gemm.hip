@@ -197,6 +197,20 @@ __global__ void axpby_kernel(double *y, const double *x, double a, double b, siz
         y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
 
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double *sink, int iters, double seed)
+{
+    v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = seed + threadIdx.x * 1e-3, y = seed - threadIdx.x * 1e-3;
+    for (int i = 0; i < iters; ++i) {
+        a0 = mfma16(x, y, a0);
+        a1 = mfma16(y, x, a1);
+        a2 = mfma16(x, x, a2);
+        a3 = mfma16(y, y, a3);
+    }
+    v4d t = a0 + a1 + a2 + a3;
+    if (t[0] + t[1] + t[2] + t[3] == 12345.678) sink[blockIdx.x] = t[0];
+}
+
 template <int BM, int BN>
 static int launch_gemm(const ttsk_gemm_desc &d, const double *A, const double *B, double *C,
                        const double *ks, int splits, int64_t kchunk, int use_atomic, bool ak, bool bk,
@@ -271,6 +285,34 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     if (bm == 64) return launch_gemm<64, 64>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
     if (bm == 32) return launch_gemm<32, 128>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
     return launch_gemm<128, 32>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
+}
+
+int ttsk_mfma_f64_peak_probe(double *tflops)
+{
+    TTSK_STREAM(st, 0);
+    TTSK_ARG(tflops, "ttsk_mfma_f64_peak_probe: NULL");
+    double *sink = (double *)scratch(0, 1 << 16);
+    if (!sink) return TTSK_ERR_HIP;
+    const int blocks = 256 * 8, iters = 2000;
+    hipEvent_t a, b;
+    TTSK_HIP(hipEventCreate(&a));
+    TTSK_HIP(hipEventCreate(&b));
+    double best = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        TTSK_HIP(hipEventRecord(a, st));
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0 + rep);
+        TTSK_HIP(hipEventRecord(b, st));
+        TTSK_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        TTSK_HIP(hipEventElapsedTime(&ms, a, b));
+        double fl = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
+        double tf = fl / (ms * 1e-3) * 1e-12;
+        if (rep > 0 && tf > best) best = tf;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *tflops = best;
+    return TTSK_OK;
 }
 
 int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *shape,
