@@ -13,149 +13,33 @@
 // conflict free and the MFMA fragment reads (ds_read_b64) hit 64 distinct banks:
 //   "m-fast": tile[k][m], ld = BM+16 (== 16 mod 32)   "k-fast": tile[m][k], ld = 18 (== 2 mod 32)
 // Split-K over (ko,ki) through gridDim.z with fp64 global atomics.
-#include "common.h"
+#include "gemm_kernel.h"
 
 namespace ttsk {
 
-constexpr int BK = 16;
-constexpr int LDK = 18;  // k-fast layout leading dimension
-
-template <int BT, bool KFAST>
-struct TileLayout {
-    static constexpr int LD = KFAST ? LDK : BT + 16;
-    static constexpr int SIZE = KFAST ? BT * LDK : BK * (BT + 16);
-    __device__ static __forceinline__ int at(int x, int k) { return KFAST ? x * LDK + k : k * LD + x; }
-};
-
-struct KMap {
-    int64_t Ko, Ki, s_ko, s_ki;
-    __device__ __forceinline__ int64_t off(int64_t kk) const
-    {
-        if (Ko == 1) return kk * s_ki;
-        int64_t ko = kk / Ki;
-        return ko * s_ko + (kk - ko * Ki) * s_ki;
-    }
-};
-
-template <int BM, int BN, bool AK, bool BKF>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const double *__restrict__ A,
-                                                       const double *__restrict__ B,
-                                                       double *__restrict__ C,
-                                                       const double *__restrict__ kscale, int splits,
-                                                       int64_t kchunk, int use_atomic)
+// C[b,m,n] (+)= alpha * sum_z partial[b*splits+z][tile(m), tile(n)][t][lane]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ttsk_gemm_desc d, const double *__restrict__ partial,
+                                                            double *__restrict__ C, int splits, int64_t tiles_m,
+                                                            int64_t tiles_n, int rota)
 {
-    using LA = TileLayout<BM, AK>;
-    using LB = TileLayout<BN, BKF>;
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;  // elements per thread per tile
-    __shared__ double As[LA::SIZE];
-    __shared__ double Bs[LB::SIZE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t bz = blockIdx.z;
-    const int64_t b = bz / splits;
-    const int z = (int)(bz - b * splits);
-    const int64_t Ktot = d.Ko * d.Ki;
-    const int64_t kbeg = (int64_t)z * kchunk;
-    const int64_t kend = (kbeg + kchunk < Ktot) ? kbeg + kchunk : Ktot;
-
-    const double *Ab = A + b * d.a_b;
-    const double *Bb = B + b * d.b_b;
-    const KMap ka{d.Ko, d.Ki, d.a_ko, d.a_ki};
-    const KMap kb{d.Ko, d.Ki, d.b_ko, d.b_ki};
-
-    v4d acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
-
-    double ra[EA], rb[EB];
-
-    auto load_tiles = [&](int64_t k0) {
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int x, k;
-            if (AK) { k = tid & 15; x = (tid >> 4) + 16 * e; }
-            else    { x = tid % BM; k = tid / BM + (256 / BM) * e; }
-            int64_t kk = k0 + k, m = m0 + x;
-            double v = 0.0;
-            if (kk < kend && m < d.M) {
-                v = Ab[m * d.a_m + ka.off(kk)];
-                if (kscale) v *= kscale[kk];
-            }
-            ra[e] = v;
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int x, k;
-            if (BKF) { k = tid & 15; x = (tid >> 4) + 16 * e; }
-            else     { x = tid % BN; k = tid / BN + (256 / BN) * e; }
-            int64_t kk = k0 + k, n = n0 + x;
-            double v = 0.0;
-            if (kk < kend && n < d.N) v = Bb[n * d.b_n + kb.off(kk)];
-            rb[e] = v;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int x, k;
-            if (AK) { k = tid & 15; x = (tid >> 4) + 16 * e; }
-            else    { x = tid % BM; k = tid / BM + (256 / BM) * e; }
-            As[LA::at(x, k)] = ra[e];
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int x, k;
-            if (BKF) { k = tid & 15; x = (tid >> 4) + 16 * e; }
-            else     { x = tid % BN; k = tid / BN + (256 / BN) * e; }
-            Bs[LB::at(x, k)] = rb[e];
-        }
-    };
-
-    const int fi = lane >> 4, fj = lane & 15;
-    if (kbeg < kend) load_tiles(kbeg);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < kend) load_tiles(k0 + BK);
-#pragma unroll
-        for (int ks = 0; ks < BK; ks += 4) {
-            double af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[LA::at(wr * WM + i * 16 + fj, ks + fi)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[LB::at(wc * WN + j * 16 + fj, ks + fi)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
-        }
+    const int64_t per_b = tiles_m * tiles_n * 256;
+    const int64_t total = d.batch * per_b;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = g / per_b, rem = g - b * per_b;
+        const int64_t tile = rem >> 8;
+        const int t = (int)((rem >> 6) & 3), lane = (int)(rem & 63);
+        const int64_t ti = tile / tiles_n, tj = tile - ti * tiles_n;
+        const int li = lane >> 4, beta = (lane >> 2) & 3, jj = lane & 3;
+        const int rb = rota ? ((beta + t) & 3) : beta, cb = rota ? beta : ((beta + t) & 3);
+        const int64_t m = ti * 16 + 4 * rb + li, n = tj * 16 + 4 * cb + jj;
+        if (m >= d.M || n >= d.N) continue;
+        const double *p = partial + (b * splits) * per_b + rem;
+        double s = 0.0;
+        for (int z = 0; z < splits; ++z) s += p[(int64_t)z * per_b];
+        double *c = C + b * d.c_b + m * d.c_m + n * d.c_n;
+        *c = d.alpha * s + (d.accumulate ? *c : 0.0);
     }
-
-    double *Cb = C + b * d.c_b;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int64_t m = m0 + wr * WM + i * 16 + fi + 4 * r;
-                int64_t n = n0 + wc * WN + j * 16 + fj;
-                if (m < d.M && n < d.N) {
-                    double v = d.alpha * acc[i][j][r];
-                    double *p = Cb + m * d.c_m + n * d.c_n;
-                    if (use_atomic) unsafeAtomicAdd(p, v);
-                    else if (d.accumulate) *p += v;
-                    else *p = v;
-                }
-            }
 }
 
 __global__ void fill3_kernel(double *C, int64_t batch, int64_t M, int64_t N, int64_t c_b, int64_t c_m,
@@ -211,24 +95,20 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *sink, int iters
     if (t[0] + t[1] + t[2] + t[3] == 12345.678) sink[blockIdx.x] = t[0];
 }
 
-template <int BM, int BN>
-static int launch_gemm(const ttsk_gemm_desc &d, const double *A, const double *B, double *C,
-                       const double *ks, int splits, int64_t kchunk, int use_atomic, bool ak, bool bk,
-                       hipStream_t st)
+struct GemmPlan {
+    int family, tiles, bm, bn;
+};
+
+static GemmPlan plan_gemm(int64_t M, int64_t N)
 {
-    dim3 grid((unsigned)cdiv(d.N, BN), (unsigned)cdiv(d.M, BM), (unsigned)(d.batch * splits));
-    dim3 block(256);
-#define L(AKV, BKV)                                                                               \
-    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AKV, BKV>), grid, block, 0, st, d, A, B, C, ks,   \
-                       splits, kchunk, use_atomic)
-    if (ak && bk) L(true, true);
-    else if (ak) L(true, false);
-    else if (bk) L(false, true);
-    else L(false, false);
-#undef L
-    TTSK_LAUNCH_CHECK();
-    return TTSK_OK;
+    GemmPlan p;
+    if (M <= 128 && M <= N) { p.family = 1; p.tiles = (int)cdiv(M, 16); p.bm = 16 * p.tiles; p.bn = 64; }
+    else if (N <= 128) { p.family = 2; p.tiles = (int)cdiv(N, 16); p.bm = 64; p.bn = 16 * p.tiles; }
+    else { p.family = 0; p.tiles = 2; p.bm = 64; p.bn = 64; }
+    return p;
 }
+
+static bool even(int64_t v) { return (v & 1) == 0; }
 
 }  // namespace ttsk
 
@@ -253,19 +133,16 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
         }
         return TTSK_OK;
     }
-    // tile shape by aspect ratio
-    int bm = 64, bn = 64;
-    if (d.M <= 32 && d.N > 64) { bm = 32; bn = 128; }
-    else if (d.N <= 32 && d.M > 64) { bm = 128; bn = 32; }
-    const int64_t tiles = d.batch * cdiv(d.M, bm) * cdiv(d.N, bn);
+    const GemmPlan p = plan_gemm(d.M, d.N);
+    const int64_t tiles = d.batch * cdiv(d.M, p.bm) * cdiv(d.N, p.bn);
     int splits = d.split_k;
     if (splits <= 0) {
         splits = 1;
-        if (tiles < 256 && K >= 256) {
-            int64_t want = cdiv(768, tiles);
-            int64_t maxs = cdiv(K, 64);
+        if (tiles < 192 && K >= 8 * BK) {
+            int64_t want = cdiv(512, tiles);
+            int64_t maxs = cdiv(K, 4 * BK);
             splits = (int)(want < maxs ? want : maxs);
-            if (splits > 512) splits = 512;
+            if (splits > 1024) splits = 1024;
             if (splits < 1) splits = 1;
         }
     }
@@ -273,25 +150,51 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
              (long long)(d.batch * splits));
     int64_t kchunk = cdiv(cdiv(K, splits), BK) * BK;
     splits = (int)cdiv(K, kchunk);
-    const int use_atomic = splits > 1;
-    if (use_atomic && !d.accumulate) {
-        hipLaunchKernelGGL(fill3_kernel, dim3(256), dim3(256), 0, st, C, d.batch, d.M, d.N, d.c_b, d.c_m,
-                           d.c_n, 0.0);
-        TTSK_LAUNCH_CHECK();
+    double *partial = nullptr;
+    const int64_t tiles_m = cdiv(d.M, p.bm) * (p.bm / 16), tiles_n = cdiv(d.N, p.bn) * (p.bn / 16);
+    if (splits > 1) {
+        partial = (double *)scratch(stream, SCRATCH_GEMM, (size_t)(d.batch * splits * tiles_m * tiles_n * 256) * 8 + 64);
+        if (!partial) return TTSK_ERR_HIP;
     }
-    // which index is contiguous in memory decides the staging layout
-    const bool ak = (d.a_m != 1) && (d.Ki == 1 ? d.a_ko == 1 || d.a_ki == 1 : d.a_ki == 1);
-    const bool bk = (d.b_n != 1) && (d.Ki == 1 ? d.b_ko == 1 || d.b_ki == 1 : d.b_ki == 1);
-    if (bm == 64) return launch_gemm<64, 64>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
-    if (bm == 32) return launch_gemm<32, 128>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
-    return launch_gemm<128, 32>(d, A, B, C, k_scale, splits, kchunk, use_atomic, ak, bk, st);
+    // normalise a single contracted index into the inner slot
+    if (d.Ki == 1) { d.Ki = d.Ko; d.Ko = 1; d.a_ki = d.a_ko; d.b_ki = d.b_ko; }
+    if (d.Ko == 1) { d.a_ko = 0; d.b_ko = 0; }
+    if (d.batch == 1) { d.a_b = 0; d.b_b = 0; }
+    // which index is contiguous in memory decides the staging layout; 16-byte loads when the
+    // contiguous index pairs up cleanly (even strides, pairs never straddle ko, aligned base)
+    const bool ak = d.a_m != 1 && d.a_ki == 1;
+    const bool bk = d.b_n != 1 && d.b_ki == 1;
+    const bool k_pairs = d.Ko == 1 || even(d.Ki);
+    int avec = ak ? (k_pairs && even(d.a_m) && even(d.a_ko) && even(d.a_b))
+                  : (d.a_m == 1 && even(d.a_ki) && even(d.a_ko) && even(d.a_b));
+    int bvec = bk ? (k_pairs && even(d.b_n) && even(d.b_ko) && even(d.b_b))
+                  : (d.b_n == 1 && even(d.b_ki) && even(d.b_ko) && even(d.b_b));
+    if (((uintptr_t)A & 15) != 0) avec = 0;
+    if (((uintptr_t)B & 15) != 0) bvec = 0;
+    // 16-byte loads additionally need whole pairs inside the extents
+    if (ak ? (K & 1) : (d.M & 1)) avec = 0;
+    if (bk ? (K & 1) : (d.N & 1)) bvec = 0;
+    GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, kchunk, p.bm, p.bn};
+    int rc;
+    if (ak && bk) rc = launch_gemm_layout<true, true>(g, st);
+    else if (ak) rc = launch_gemm_layout<true, false>(g, st);
+    else if (bk) rc = launch_gemm_layout<false, true>(g, st);
+    else rc = launch_gemm_layout<false, false>(g, st);
+    if (rc || !partial) return rc;
+    const int64_t total = d.batch * tiles_m * tiles_n * 256;
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, partial, C, splits,
+                       tiles_m, tiles_n, p.family == 2 ? 1 : 0);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
 }
 
 int ttsk_mfma_f64_peak_probe(double *tflops)
 {
     TTSK_STREAM(st, 0);
     TTSK_ARG(tflops, "ttsk_mfma_f64_peak_probe: NULL");
-    double *sink = (double *)scratch(0, 1 << 16);
+    double *sink = (double *)scratch(0, SCRATCH_GEMM, 1 << 16);
     if (!sink) return TTSK_ERR_HIP;
     const int blocks = 256 * 8, iters = 2000;
     hipEvent_t a, b;

@@ -241,7 +241,7 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
         if (rcond < floor_) rcond = floor_;
     }
     const size_t ws_elems = (size_t)(mW * nW + nW * nW) + 1;
-    double *ws = (double *)scratch(stream, ws_elems * 8);
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, ws_elems * 8);
     if (!ws) return TTSK_ERR_HIP;
     int *drank = (int *)(ws + mW * nW + nW * nW);
     hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_omega, l, r, transposed, ws,
@@ -264,7 +264,7 @@ int ttsk_qr_thin(double *A, int64_t m, int64_t n, int stream)
     // scratch: tpart[n][nb] (tail-norm partials per pivot column), wpart[nb][n], Q[m*n]
     const int64_t nb = cdiv(m, QR_ROWS);
     const size_t small = (size_t)n * nb + (size_t)nb * n;
-    double *ws = (double *)scratch(stream, (small + (size_t)m * n) * 8);
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, (small + (size_t)m * n) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *tpart = ws, *wpart = ws + (size_t)n * nb, *Q = ws + small;
     auto blocks_at = [&](int64_t j) { return (int)cdiv(m - j, QR_ROWS); };

@@ -30,28 +30,29 @@ int ensure_init()
 // Grow-only scratch arena per library stream.  (hipMallocAsync's stream-ordered pool returned
 // buffers that were corrupted under us on ROCm 7.2 / gfx950 -- measured with the QR kernels --
 // so temporaries come from plain hipMalloc and are reused in stream order.)
-static void *g_scratch[TTSK_NUM_STREAMS];
-static size_t g_scratch_bytes[TTSK_NUM_STREAMS];
+static void *g_scratch[TTSK_NUM_STREAMS][SCRATCH_SLOTS];
+static size_t g_scratch_bytes[TTSK_NUM_STREAMS][SCRATCH_SLOTS];
 
-void *scratch(int s, size_t bytes)
+void *scratch(int s, int slot, size_t bytes)
 {
-    if (ensure_init() != TTSK_OK || s < 0 || s >= TTSK_NUM_STREAMS) return nullptr;
-    if (bytes <= g_scratch_bytes[s]) return g_scratch[s];
-    if (g_scratch[s]) {
+    if (ensure_init() != TTSK_OK || s < 0 || s >= TTSK_NUM_STREAMS || slot < 0 || slot >= SCRATCH_SLOTS)
+        return nullptr;
+    if (bytes <= g_scratch_bytes[s][slot]) return g_scratch[s][slot];
+    if (g_scratch[s][slot]) {
         (void)hipStreamSynchronize(g_streams[s]);
-        (void)hipFree(g_scratch[s]);
-        g_scratch[s] = nullptr;
-        g_scratch_bytes[s] = 0;
+        (void)hipFree(g_scratch[s][slot]);
+        g_scratch[s][slot] = nullptr;
+        g_scratch_bytes[s][slot] = 0;
     }
     size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipMalloc(&g_scratch[s], want);
+    hipError_t e = hipMalloc(&g_scratch[s][slot], want);
     if (e != hipSuccess) {
         set_error("scratch allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
-        g_scratch[s] = nullptr;
+        g_scratch[s][slot] = nullptr;
         return nullptr;
     }
-    g_scratch_bytes[s] = want;
-    return g_scratch[s];
+    g_scratch_bytes[s][slot] = want;
+    return g_scratch[s][slot];
 }
 
 hipStream_t stream_of(int s)
@@ -108,9 +109,11 @@ int ttsk_shutdown(void)
         (void)hipEventDestroy(g_ev_start[i]);
         (void)hipEventDestroy(g_ev_stop[i]);
         (void)hipEventDestroy(g_ev_sync[i]);
-        if (g_scratch[i]) (void)hipFree(g_scratch[i]);
-        g_scratch[i] = nullptr;
-        g_scratch_bytes[i] = 0;
+        for (int k = 0; k < SCRATCH_SLOTS; ++k) {
+            if (g_scratch[i][k]) (void)hipFree(g_scratch[i][k]);
+            g_scratch[i][k] = nullptr;
+            g_scratch_bytes[i][k] = 0;
+        }
     }
     g_init = false;
     g_device = -1;

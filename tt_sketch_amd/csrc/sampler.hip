@@ -218,7 +218,7 @@ static int sign_dev(const int64_t *dev_idx, const IndexMap &im, size_t N, int tr
     TTSK_ARG(0 <= rank_min && rank_min <= rank_max && rank_max <= true_rank,
              "sparse sign: bad rank slice [%d,%d) of %d", rank_min, rank_max, true_rank);
     if (N == 0 || rank_max == rank_min) return TTSK_OK;
-    int8_t *ws = (int8_t *)scratch(stream, N * (size_t)true_rank);
+    int8_t *ws = (int8_t *)scratch(stream, SCRATCH_MISC, N * (size_t)true_rank);
     if (!ws) return TTSK_ERR_HIP;
     hipLaunchKernelGGL((sign_kernel<OUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dev_idx, im,
                        N, true_rank, nnz, rank_min, rank_max, seed, ws, dev_out);

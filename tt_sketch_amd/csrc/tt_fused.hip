@@ -123,7 +123,7 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         if (mu < d) tmax = tl > tmax ? tl : tmax;
         if (mu < d - 1) tmax = tr > tmax ? tr : tmax;
     }
-    double *ws = (double *)scratch(stream, (tot + tmax) * 8);
+    double *ws = (double *)scratch(stream, SCRATCH_DRIVER, (tot + tmax) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *T = ws + tot;
     int rc;
