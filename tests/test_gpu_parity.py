@@ -38,7 +38,13 @@ def test_contract_against_einsum(tsa):
              ("ij,ikl->jkl", (23, 11), (23, 9, 17)), ("jkl,jkm->lm", (11, 9, 17), (11, 9, 13)),
              ("ijk,ijl->kl", (1, 19, 7), (1, 19, 5)), ("ki,ikl->il", (9, 6), (6, 9, 4)),
              ("kj,jm->jkm", (8, 5), (5, 7)), ("ij,jkl->ikl", (300, 70), (70, 3, 5)),
-             ("ie,je->ij", (6, 5000), (9, 5000)), ("ijk,jl->ilk", (4, 6, 5), (6, 8))]
+             ("ie,je->ij", (6, 5000), (9, 5000)), ("ijk,jl->ilk", (4, 6, 5), (6, 8)),
+             # every kernel family x odd / even extents x split-K (M or N <= 128: skinny families)
+             ("ie,je->ij", (7, 5040), (5, 5040)), ("ie,je->ij", (8, 5041), (5, 5041)),
+             ("ij,jk->ik", (100, 100), (100, 20000)), ("ij,jk->ik", (333, 100), (100, 101)),
+             ("ij,jk->ik", (130, 257), (257, 131)), ("ji,jk->ik", (4001, 50), (4001, 51)),
+             ("ij,jk->ik", (17, 33), (33, 4099)), ("ij,kj->ik", (4099, 35), (18, 35)),
+             ("jlk,jkm->lm", (11, 13, 45), (11, 45, 7)), ("jkl,jkm->lm", (50, 40, 30), (50, 40, 20))]
     for spec, sa, sb in specs:
         A, B = rng.standard_normal(sa), rng.standard_normal(sb)
         got = contract(spec, DevArray.from_host(A), DevArray.from_host(B)).get()

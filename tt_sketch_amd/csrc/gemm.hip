@@ -18,27 +18,45 @@
 namespace ttsk {
 
 // C[b,m,n] (+)= alpha * sum_z partial[b*splits+z][tile(m), tile(n)][t][lane]
+// 256 threads = 64 consecutive partial elements x 4 interleaved z-lanes, 4 independent loads in
+// flight per thread, LDS combine: the sum over ~100 slabs costs ~8 dependent round trips, not 100.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ttsk_gemm_desc d, const double *__restrict__ partial,
                                                             double *__restrict__ C, int splits, int64_t tiles_m,
                                                             int64_t tiles_n, int rota)
 {
+    __shared__ double red[4][64];
     const int64_t per_b = tiles_m * tiles_n * 256;
     const int64_t total = d.batch * per_b;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = g / per_b, rem = g - b * per_b;
-        const int64_t tile = rem >> 8;
-        const int t = (int)((rem >> 6) & 3), lane = (int)(rem & 63);
-        const int64_t ti = tile / tiles_n, tj = tile - ti * tiles_n;
-        const int li = lane >> 4, beta = (lane >> 2) & 3, jj = lane & 3;
-        const int rb = rota ? ((beta + t) & 3) : beta, cb = rota ? beta : ((beta + t) & 3);
-        const int64_t m = ti * 16 + 4 * rb + li, n = tj * 16 + 4 * cb + jj;
-        if (m >= d.M || n >= d.N) continue;
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int64_t g0 = (int64_t)blockIdx.x * 64; g0 < total; g0 += (int64_t)gridDim.x * 64) {
+        const int64_t idx = g0 + e;                 // per_b is a multiple of 256: a group never straddles b
+        const int64_t b = idx / per_b, rem = idx - b * per_b;
         const double *p = partial + (b * splits) * per_b + rem;
-        double s = 0.0;
-        for (int z = 0; z < splits; ++z) s += p[(int64_t)z * per_b];
-        double *c = C + b * d.c_b + m * d.c_m + n * d.c_n;
-        *c = d.alpha * s + (d.accumulate ? *c : 0.0);
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int z = g;
+        for (; z + 12 < splits; z += 16) {
+            s0 += p[(int64_t)z * per_b];
+            s1 += p[(int64_t)(z + 4) * per_b];
+            s2 += p[(int64_t)(z + 8) * per_b];
+            s3 += p[(int64_t)(z + 12) * per_b];
+        }
+        for (; z < splits; z += 4) s0 += p[(int64_t)z * per_b];
+        red[g][e] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0) {
+            const double s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            const int64_t tile = rem >> 8;
+            const int t = (int)((rem >> 6) & 3), lane = (int)(rem & 63);
+            const int64_t ti = tile / tiles_n, tj = tile - ti * tiles_n;
+            const int li = lane >> 4, beta = (lane >> 2) & 3, jj = lane & 3;
+            const int rb = rota ? ((beta + t) & 3) : beta, cb = rota ? beta : ((beta + t) & 3);
+            const int64_t m = ti * 16 + 4 * rb + li, n = tj * 16 + 4 * cb + jj;
+            if (m < d.M && n < d.N) {
+                double *c = C + b * d.c_b + m * d.c_m + n * d.c_n;
+                *c = d.alpha * s + (d.accumulate ? *c : 0.0);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -138,9 +156,9 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     int splits = d.split_k;
     if (splits <= 0) {
         splits = 1;
-        if (tiles < 192 && K >= 8 * BK) {
+        if (tiles < 192 && K >= 4 * BK) {
             int64_t want = cdiv(512, tiles);
-            int64_t maxs = cdiv(K, 4 * BK);
+            int64_t maxs = cdiv(K, K >= 32 * BK ? 4 * BK : BK);
             splits = (int)(want < maxs ? want : maxs);
             if (splits > 1024) splits = 1024;
             if (splits < 1) splits = 1;
@@ -174,7 +192,11 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     // 16-byte loads additionally need whole pairs inside the extents
     if (ak ? (K & 1) : (d.M & 1)) avec = 0;
     if (bk ? (K & 1) : (d.N & 1)) bvec = 0;
-    GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, kchunk, p.bm, p.bn};
+    // the fast staging path addresses a tile as uniform base + 32-bit byte offset
+    const int64_t span_a = (int64_t)p.bm * d.a_m + BK * d.a_ki, span_b = (int64_t)p.bn * d.b_n + BK * d.b_ki;
+    const int fast_ok = d.a_m >= 0 && d.b_n >= 0 && d.a_ki >= 0 && d.b_ki >= 0 && span_a * 8 < (1ll << 31) &&
+                        span_b * 8 < (1ll << 31);
+    GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, fast_ok, kchunk, p.bm, p.bn};
     int rc;
     if (ak && bk) rc = launch_gemm_layout<true, true>(g, st);
     else if (ak) rc = launch_gemm_layout<true, false>(g, st);
@@ -182,8 +204,8 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     else rc = launch_gemm_layout<false, false>(g, st);
     if (rc || !partial) return rc;
     const int64_t total = d.batch * tiles_m * tiles_n * 256;
-    int64_t blocks = cdiv(total, 256);
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = cdiv(total, 64);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, partial, C, splits,
                        tiles_m, tiles_n, p.family == 2 ? 1 : 0);
     TTSK_LAUNCH_CHECK();

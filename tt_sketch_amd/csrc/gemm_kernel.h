@@ -53,15 +53,23 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
 }
 
 // One operand tile: global -> registers -> LDS.  X = the non-contracted index (m or n).
-// Loads are branch free: indices are clamped into the valid range and the value is zeroed by a
-// select afterwards, so the compiler can issue all of a tile's loads back to back behind a
-// single wait (a per-element `if` makes hipcc wait for every load separately).  All divisions
-// happen once in init(); per K-tile the (ko, ki) split of the tile origin is wave-uniform.
+//
+// Fast path (interior K-tiles, offsets below 2 GB): every pair of the tile is one
+// `global_load_dwordx4 v, v_off, s[base]` -- a wave-uniform base pointer that the scalar unit
+// advances per K-tile plus a per-thread 32-bit byte offset computed once in init().  No vector
+// ALU work per load, which matters because the fp64 MFMA rate is so low on this part that a
+// few VALU instructions per MFMA already set the pace (measured: 4.3 VALU per MFMA cost 60 %).
+// Row / column overhang is handled by clamping the offset in init() and zeroing at the LDS
+// store.  Slow path (K tail, tiles that straddle two `ko` slices, > 2 GB strides): branch-free
+// clamped loads with full index arithmetic.
 template <bool KF, int NE2>
 struct Stager {
     double2 r[NE2];
-    int xk[NE2];  // x | k << 16 of the first element of pair e, -1 if the pair is outside the tile
-    __device__ __forceinline__ void init(int bx, int tid)
+    uint32_t goff[NE2];  // byte offset of the pair from the tile base (x clamped), K-tile relative
+    int lds[NE2];        // LDS offset [15:0] | k [21:16] | pair-element-1 invalid [28] | element-0 invalid [29];
+                         // negative: pair not in the tile
+    __device__ __forceinline__ void init(int bx, int ld, int tid, int64_t x0, int64_t X, int64_t xs,
+                                         int64_t s_ki)
     {
         const int half = KF ? BK / 2 : bx / 2;
 #pragma unroll
@@ -70,84 +78,98 @@ struct Stager {
             int x, k;
             if (KF) { k = 2 * (idx % (BK / 2)); x = idx / (BK / 2); }
             else    { x = 2 * (idx % half); k = idx / half; }
-            xk[e] = (x < bx && k < BK) ? (x | (k << 16)) : -1;
+            if (x < bx && k < BK) {
+                const int64_t gx = x0 + x;
+                const int x1 = KF ? x : x + 1;
+                const bool in0 = gx < X, in1 = x0 + x1 < X;
+                // clamp so that even a masked-out pair reads valid memory
+                int64_t cx = gx;
+                if (gx >= X) {
+                    cx = KF ? X - 1 : X - 2;      // a whole pair that exists (16-byte loads need X even)
+                    if (cx < x0) cx = x0;
+                }
+                goff[e] = (uint32_t)(((cx - x0) * xs + (int64_t)k * s_ki) * 8);
+                lds[e] = (KF ? x * LDKF + k : k * ld + x) | (k << 16) | (in0 ? 0 : 0x20000000) | (in1 ? 0 : 0x10000000);
+            } else {
+                goff[e] = 0;
+                lds[e] = -1;
+            }
         }
     }
-    __device__ __forceinline__ int64_t koff(const KMap &km, int64_t ko0, int64_t ki0, int k) const
+    // Fast path: base = address of tile element (x0, k0).  second_off: byte distance between the two
+    // elements of a pair when 16-byte loads are not possible.
+    __device__ __forceinline__ void load_fast(const char *__restrict__ base, bool vec, uint32_t second_off)
     {
-        if (km.Ko == 1) return (ki0 + k) * km.s_ki;
-        int64_t ki = ki0 + k, ko = ko0;
-        if (km.Ki >= BK) {          // at most one wrap inside a tile
-            const bool w = ki >= km.Ki;
-            ki -= w ? km.Ki : 0;
-            ko += w ? 1 : 0;
-        } else {
-            const int64_t q = ki / km.Ki;
-            ko += q;
-            ki -= q * km.Ki;
-        }
-        return ko * km.s_ko + ki * km.s_ki;
-    }
-    // pair e covers tile elements (x, k),(x, k+1) [KF] or (x, k),(x+1, k) [m-fast]
-    __device__ __forceinline__ void load(const double *__restrict__ P, int64_t xs, const KMap &km, int64_t x0,
-                                         int64_t X, int64_t k0, int64_t kend, bool vec,
-                                         const double *__restrict__ kscale)
-    {
-        int64_t ko0 = 0, ki0 = k0;
-        if (km.Ko != 1) { ko0 = k0 / km.Ki; ki0 = k0 - ko0 * km.Ki; }
-        const int64_t xlast = X - 1, klast = kend - 1 - k0;   // clamps (tile-relative for k)
         if (vec) {
 #pragma unroll
-            for (int e = 0; e < NE2; ++e) {
-                const int x = xk[e] & 0xFFFF, k = (xk[e] >> 16) & 0x7FFF;
-                // vec is only set when extents are even: a pair is inside or outside as a whole
-                int64_t gx = x0 + x;
-                int kc = k;
-                const bool in = xk[e] >= 0 && gx < X && k <= klast;
-                gx = gx < X ? gx : (KF ? xlast : xlast - 1);
-                kc = kc <= klast ? kc : (int)(KF ? klast - 1 : klast);
-                const double2 v = *reinterpret_cast<const double2 *>(P + gx * xs + koff(km, ko0, ki0, kc));
-                r[e].x = in ? v.x : 0.0;
-                r[e].y = in ? v.y : 0.0;
-            }
+            for (int e = 0; e < NE2; ++e) r[e] = *reinterpret_cast<const double2 *>(base + goff[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < NE2; ++e) {
-                const int x = xk[e] & 0xFFFF, k = (xk[e] >> 16) & 0x7FFF;
-                const int64_t gx = x0 + x, gx1 = KF ? gx : gx + 1;
-                const int k1 = KF ? k + 1 : k;
-                const bool in0 = xk[e] >= 0 && gx < X && k <= klast;
-                const bool in1 = xk[e] >= 0 && gx1 < X && k1 <= klast;
-                const int64_t cx0 = gx < X ? gx : xlast, cx1 = gx1 < X ? gx1 : xlast;
-                const int ck0 = k <= klast ? k : (int)klast, ck1 = k1 <= klast ? k1 : (int)klast;
-                const double v0 = P[cx0 * xs + koff(km, ko0, ki0, ck0)];
-                const double v1 = P[cx1 * xs + koff(km, ko0, ki0, ck1)];
-                r[e].x = in0 ? v0 : 0.0;
-                r[e].y = in1 ? v1 : 0.0;
-            }
-        }
-        if (kscale) {
-#pragma unroll
-            for (int e = 0; e < NE2; ++e) {
-                const int k = (xk[e] >> 16) & 0x7FFF;
-                const int k1 = KF ? k + 1 : k;
-                const int ck0 = k <= klast ? k : (int)klast, ck1 = k1 <= klast ? k1 : (int)klast;
-                r[e].x *= kscale[k0 + ck0];
-                r[e].y *= kscale[k0 + ck1];
+                r[e].x = *reinterpret_cast<const double *>(base + goff[e]);
+                r[e].y = *reinterpret_cast<const double *>(base + goff[e] + ((lds[e] & 0x10000000) ? 0u : second_off));
             }
         }
     }
-    __device__ __forceinline__ void store(double *S, int ld) const
+    // K tail (kcount < BK valid k) and tiles that straddle two `ko` slices (ki0 + k wraps at Ki):
+    // same loads with a per-element K adjustment; scalar 8-byte loads, the pair may split.
+    __device__ __forceinline__ void load_adj(const char *__restrict__ base, uint32_t second_off, int kcount,
+                                             int64_t ki0, int64_t Ki, int64_t s_ki, int64_t s_ko)
+    {
+        const int64_t wrap = (s_ko - Ki * s_ki) * 8;
+#pragma unroll
+        for (int e = 0; e < NE2; ++e) {
+            const int k = (lds[e] >> 16) & 63;
+            const int k1 = KF ? k + 1 : k;
+            const int c0 = k < kcount ? k : kcount - 1, c1 = k1 < kcount ? k1 : kcount - 1;
+            // goff holds x-part + k*s_ki*8; re-base the k part on the clamped / wrapped index
+            const int64_t o0 = (int64_t)goff[e] + (int64_t)(c0 - k) * s_ki * 8 + ((ki0 + c0 >= Ki) ? wrap : 0);
+            int64_t o1 = (int64_t)goff[e] + (int64_t)(c1 - k) * s_ki * 8 + ((ki0 + c1 >= Ki) ? wrap : 0);
+            if (!KF) o1 += (lds[e] & 0x10000000) ? 0 : second_off;
+            r[e].x = *reinterpret_cast<const double *>(base + o0);
+            r[e].y = *reinterpret_cast<const double *>(base + o1);
+        }
+    }
+    __device__ __forceinline__ void store(double *S, bool edge, int kcount) const
     {
 #pragma unroll
         for (int e = 0; e < NE2; ++e) {
-            if (xk[e] >= 0) {
-                const int x = xk[e] & 0xFFFF, k = xk[e] >> 16;
-                *reinterpret_cast<double2 *>(S + (KF ? x * LDKF + k : k * ld + x)) = r[e];
+            if (lds[e] >= 0) {
+                double2 v = r[e];
+                if (edge) {
+                    const int k = (lds[e] >> 16) & 63;
+                    if ((lds[e] & 0x20000000) || k >= kcount) v.x = 0.0;
+                    if ((lds[e] & 0x10000000) || (KF ? k + 1 : k) >= kcount) v.y = 0.0;
+                }
+                *reinterpret_cast<double2 *>(S + (lds[e] & 0xFFFF)) = v;
             }
         }
     }
 };
+
+// Slow path of the staging (K tail, tiles that straddle two `ko` slices, strides beyond the 32-bit
+// offset range, k_scale): a rolled loop straight from global memory into the LDS tile with full
+// index arithmetic.  Deliberately NOT unrolled: the hot loop has to stay inside the instruction
+// cache (an earlier fully unrolled variant was 13k instructions and ran 3x slower).
+template <bool KF>
+__device__ __noinline__ void slow_fill(double *S, const double *__restrict__ P, int64_t xs, KMap km, int64_t x0,
+                                       int64_t X, int64_t k0, int64_t kend, int bx, int ld,
+                                       const double *__restrict__ kscale, int tid)
+{
+#pragma unroll 4
+    for (int idx = tid; idx < bx * BK; idx += 256) {
+        int x, k;
+        if (KF) { k = idx % BK; x = idx / BK; }
+        else    { x = idx % bx; k = idx / bx; }
+        const int64_t gx = x0 + x, gk = k0 + k;
+        double v = 0.0;
+        if (gx < X && gk < kend) {
+            v = P[gx * xs + km.off(gk)];
+            if (kscale) v *= kscale[gk];
+        }
+        S[KF ? x * LDKF + k : k * ld + x] = v;
+    }
+}
 
 // WM x WN waves, each owning TMX x TNX MFMA tiles of 16x16 (exact, compile time).
 template <int WM, int WN, int TMX, int TNX, bool AKF, bool BKF>
@@ -155,11 +177,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
                                                        const double *__restrict__ B, double *__restrict__ C,
                                                        const double *__restrict__ kscale, int splits,
                                                        int64_t kchunk, double *__restrict__ partial,
-                                                       int avec, int bvec)
+                                                       int avec, int bvec, int fast_ok)
 {
-    constexpr int tm = TMX, tn = TNX;
     static_assert(WM * WN == 4, "256 threads");
-    constexpr bool ROTA = TMX < TNX;  // rotate the operand with fewer tiles per wave
+    constexpr int tm = TMX, tn = TNX;
+    constexpr bool ROTA = WM > WN;    // skinny-N family: one A tile per wave, rotate it
     constexpr int NEA = WM * TMX, NEB = WN * TNX;  // double2 per thread: 16 t W * 32 / 256 / 2
     extern __shared__ double smem[];
     constexpr int bm = WM * tm * 16, bn = WN * tn * 16;
@@ -180,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
     const double *Bb = B + b * d.b_b;
     const KMap ka{d.Ko, d.Ki, d.a_ko, d.a_ki};
     const KMap kb{d.Ko, d.Ki, d.b_ko, d.b_ki};
+    const bool edge_a = m0 + bm > d.M, edge_b = n0 + bn > d.N;
 
     double acc[TMX][TNX][4];
 #pragma unroll
@@ -191,24 +214,57 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
 
     Stager<AKF, NEA> sa;
     Stager<BKF, NEB> sb;
-    const int fi = lane >> 4, fj = lane & 15;
-    sa.init(bm, tid);
-    sb.init(bn, tid);
-    if (kbeg < kend) {
-        sa.load(Ab, d.a_m, ka, m0, d.M, kbeg, kend, avec, kscale);
-        sb.load(Bb, d.b_n, kb, n0, d.N, kbeg, kend, bvec, nullptr);
-    }
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        sa.store(As, lda);
-        sb.store(Bs, ldb);
-        __syncthreads();
-        if (k0 + BK < kend) {
-            sa.load(Ab, d.a_m, ka, m0, d.M, k0 + BK, kend, avec, kscale);
-            sb.load(Bb, d.b_n, kb, n0, d.N, k0 + BK, kend, bvec, nullptr);
+    sa.init(bm, lda, tid, m0, d.M, d.a_m, d.a_ki);
+    sb.init(bn, ldb, tid, n0, d.N, d.b_n, d.b_ki);
+    const uint32_t a2 = (uint32_t)((AKF ? d.a_ki : d.a_m) * 8), b2 = (uint32_t)((BKF ? d.b_ki : d.b_n) * 8);
+    const char *a_base = reinterpret_cast<const char *>(Ab + m0 * d.a_m);
+    const char *b_base = reinterpret_cast<const char *>(Bb + n0 * d.b_n);
+
+    // Staging modes per K-tile: 2 = pure fast path, 1 = fast path with K adjustment (tail /
+    // ko-straddle), 0 = rolled generic fill (k_scale, tiny Ki, offsets beyond 32 bits).
+    auto mode_of = [&](int64_t k0) -> int {
+        if (!fast_ok || kscale) return 0;
+        const bool full = k0 + BK <= kend;
+        if (d.Ko == 1) return full ? 2 : 1;
+        if (d.Ki < BK) return 0;
+        const int64_t ki0 = k0 % d.Ki;
+        return (full && ki0 + BK <= d.Ki) ? 2 : 1;
+    };
+    auto prefetch = [&](int64_t k0, int mode) {
+        int64_t ko0 = 0, ki0 = k0;
+        if (d.Ko != 1) { ko0 = k0 / d.Ki; ki0 = k0 - ko0 * d.Ki; }
+        const char *pa = a_base + (ko0 * d.a_ko + ki0 * d.a_ki) * 8;
+        const char *pb = b_base + (ko0 * d.b_ko + ki0 * d.b_ki) * 8;
+        if (mode == 2) {
+            sa.load_fast(pa, avec, a2);
+            sb.load_fast(pb, bvec, b2);
+        } else {
+            const int kc = (int)((kend - k0 < BK) ? kend - k0 : BK);
+            const int64_t Ki = d.Ko == 1 ? (int64_t)1 << 60 : d.Ki;
+            sa.load_adj(pa, a2, kc, ki0, Ki, d.a_ki, d.a_ko);
+            sb.load_adj(pb, b2, kc, ki0, Ki, d.b_ki, d.b_ko);
         }
+    };
+
+    const int fi = lane >> 4, fj = lane & 15;
+    int cur_mode = kbeg < kend ? mode_of(kbeg) : 0;
+    if (cur_mode) prefetch(kbeg, cur_mode);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        const int kcount = (int)((kend - k0 < BK) ? kend - k0 : BK);
+        __syncthreads();
+        if (cur_mode) {
+            sa.store(As, edge_a || cur_mode == 1, kcount);
+            sb.store(Bs, edge_b || cur_mode == 1, kcount);
+        } else {
+            slow_fill<AKF>(As, Ab, d.a_m, ka, m0, d.M, k0, kend, bm, lda, kscale, tid);
+            slow_fill<BKF>(Bs, Bb, d.b_n, kb, n0, d.N, k0, kend, bn, ldb, nullptr, tid);
+        }
+        __syncthreads();
+        cur_mode = k0 + BK < kend ? mode_of(k0 + BK) : 0;
+        if (cur_mode) prefetch(k0 + BK, cur_mode);
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
+            if (ks >= kcount) break;
             double af[TMX], bf[TNX];
 #pragma unroll
             for (int i = 0; i < TMX; ++i) {
@@ -223,30 +279,22 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
             if (ROTA) {
 #pragma unroll
                 for (int i = 0; i < TMX; ++i) {
-                    if (i < tm) {
-                        double ar[4];
-                        rot4(af[i], ar);
+                    double ar[4];
+                    rot4(af[i], ar);
 #pragma unroll
-                        for (int j = 0; j < TNX; ++j)
-                            if (j < tn) {
+                    for (int j = 0; j < TNX; ++j)
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(ar[t], bf[j], acc[i][j][t]);
-                            }
-                    }
+                        for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(ar[t], bf[j], acc[i][j][t]);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < TNX; ++j) {
-                    if (j < tn) {
-                        double br[4];
-                        rot4(bf[j], br);
+                    double br[4];
+                    rot4(bf[j], br);
 #pragma unroll
-                        for (int i = 0; i < TMX; ++i)
-                            if (i < tm) {
+                    for (int i = 0; i < TMX; ++i)
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(af[i], br[t], acc[i][j][t]);
-                            }
-                    }
+                        for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(af[i], br[t], acc[i][j][t]);
                 }
             }
         }
@@ -260,38 +308,35 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
 #pragma unroll
         for (int i = 0; i < TMX; ++i)
 #pragma unroll
-            for (int j = 0; j < TNX; ++j)
-                if (i < tm && j < tn) {
-                    const int64_t ti = (int64_t)blockIdx.y * WM * tm + wr * tm + i;
-                    const int64_t tj = (int64_t)blockIdx.x * WN * tn + wc * tn + j;
-                    double *pt = pz + (ti * tiles_n + tj) * 256;
+            for (int j = 0; j < TNX; ++j) {
+                const int64_t ti = (int64_t)blockIdx.y * WM * tm + wr * tm + i;
+                const int64_t tj = (int64_t)blockIdx.x * WN * tn + wc * tn + j;
+                double *pt = pz + (ti * tiles_n + tj) * 256;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pt[t * 64 + lane] = acc[i][j][t];
-                }
+                for (int t = 0; t < 4; ++t) pt[t * 64 + lane] = acc[i][j][t];
+            }
         return;
     }
-    double *Cb = C + b * d.c_b;
     const int li = lane >> 4, beta = (lane >> 2) & 3, jj = lane & 3;
+    // element (row, col) of accumulator t of tile (i, j): see the layout note at the top
+    double *Cw = C + b * d.c_b + (m0 + wr * tm * 16 + li) * d.c_m + (n0 + wc * tn * 16 + jj) * d.c_n;
+    const int64_t mrem = d.M - (m0 + wr * tm * 16 + li), nrem = d.N - (n0 + wc * tn * 16 + jj);
 #pragma unroll
     for (int i = 0; i < TMX; ++i)
 #pragma unroll
         for (int j = 0; j < TNX; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (i < tm && j < tn) {
-                    const int rb = ROTA ? ((beta + t) & 3) : beta, cb = ROTA ? beta : ((beta + t) & 3);
-                    const int64_t m = m0 + (wr * tm + i) * 16 + 4 * rb + li;
-                    const int64_t n = n0 + (wc * tn + j) * 16 + 4 * cb + jj;
-                    if (m < d.M && n < d.N) {
-                        double v = d.alpha * acc[i][j][t];
-                        double *p = Cb + m * d.c_m + n * d.c_n;
-                        if (d.accumulate) *p += v;
-                        else *p = v;
-                    }
+                const int rb = ROTA ? ((beta + t) & 3) : beta, cb = ROTA ? beta : ((beta + t) & 3);
+                const int dm = i * 16 + 4 * rb, dn = j * 16 + 4 * cb;
+                if (dm < mrem && dn < nrem) {
+                    double v = d.alpha * acc[i][j][t];
+                    double *p = Cw + dm * d.c_m + dn * d.c_n;
+                    if (d.accumulate) *p += v;
+                    else *p = v;
                 }
             }
 }
-
 
 // launcher generated per staging-layout pair in gemm_inst_*.hip
 struct GemmLaunch {
@@ -299,7 +344,7 @@ struct GemmLaunch {
     const double *A, *B, *ks;
     double *C, *partial;
     int family, tiles;      // family 0: 2x2 waves of 2x2 tiles; 1: 1x4 waves of tiles x 1; 2: 4x1 waves of 1 x tiles
-    int splits, avec, bvec;
+    int splits, avec, bvec, fast_ok;
     int64_t kchunk;
     int bm, bn;
 };
@@ -312,7 +357,7 @@ static int launch_one(const GemmLaunch &g, hipStream_t st)
     dim3 grid((unsigned)cdiv(g.d.N, bn), (unsigned)cdiv(g.d.M, bm), (unsigned)(g.d.batch * g.splits));
     const size_t lds = 8 * (size_t)((AKF ? bm * LDKF : BK * ldmf(bm)) + (BKF ? bn * LDKF : BK * ldmf(bn)));
     hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, TMX, TNX, AKF, BKF>), grid, dim3(256), lds, st, g.d, g.A, g.B, g.C,
-                       g.ks, g.splits, g.kchunk, g.partial, g.avec, g.bvec);
+                       g.ks, g.splits, g.kchunk, g.partial, g.avec, g.bvec, g.fast_ok);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

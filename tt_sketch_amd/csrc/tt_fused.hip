@@ -112,42 +112,75 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         TTSK_ARG(0 <= r_lo[mu] && r_lo[mu] <= r_hi[mu] && r_hi[mu] <= rt[mu + 1],
                  "ttsk_tt_sketch: right rank slice %d out of range", mu);
     }
-    // workspace: Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]), T (max over modes)
-    size_t tot = 0, tmax = 0;
-    std::vector<size_t> offL(d - 1), offR(d - 1);
+    // The right chain runs on the caller's stream, the left chain on a helper stream (the two are
+    // independent until Psi / Omega need both); the Psi products are then dealt over both.  The
+    // helper is forked from / joined into `stream`, so callers (and hipGraph capture) see one stream.
+    const int aux = (stream + 1) % TTSK_NUM_STREAMS;
+    TTSK_STREAM(st_aux, aux);
+    (void)st_aux;
+    // workspace (per stream slot DRIVER of `stream`): Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]),
+    // one T buffer per left mode (kept for the Psi phase) and one T buffer for the right chain
+    size_t tot = 0;
+    std::vector<size_t> offL(d - 1), offR(d - 1), offT(d);
     for (int mu = 0; mu < d - 1; ++mu) { offL[mu] = tot; tot += (size_t)s[mu + 1] * lt[mu + 1]; }
     for (int j = 0; j < d - 1; ++j) { offR[j] = tot; tot += (size_t)s[d - 1 - j] * rt[j + 1]; }
-    for (int mu = 1; mu < d; ++mu) {
-        size_t tl = (size_t)lt[mu] * n[mu] * s[mu + 1];              // left step / Psi at mode mu
-        size_t tr = (size_t)rt[d - 1 - mu] * n[mu] * s[mu];          // right step at mode mu (j = d-1-mu)
-        if (mu < d) tmax = tl > tmax ? tl : tmax;
-        if (mu < d - 1) tmax = tr > tmax ? tr : tmax;
+    for (int mu = 1; mu < d; ++mu) { offT[mu] = tot; tot += (size_t)lt[mu] * n[mu] * s[mu + 1]; }
+    size_t tr_max = 0;
+    for (int mu = 1; mu < d - 1; ++mu) {
+        size_t tr = (size_t)rt[d - 1 - mu] * n[mu] * s[mu];
+        tr_max = tr > tr_max ? tr : tr_max;
     }
-    double *ws = (double *)scratch(stream, SCRATCH_DRIVER, (tot + tmax) * 8);
+    const size_t offTR = tot;
+    tot += tr_max;
+    double *ws = (double *)scratch(stream, SCRATCH_DRIVER, tot * 8);
     if (!ws) return TTSK_ERR_HIP;
-    double *T = ws + tot;
     int rc;
 #define CK(x) do { rc = (x); if (rc) return rc; } while (0)
+    CK(ttsk_stream_wait(aux, stream));   // fork
 
-    // ---- right chain: walks modes d-1, d-2, ..., 1 on the transposed tensor (views only).
+    // ---- right chain (stream): walks modes d-1, ..., 1 on the transposed tensor (views only).
     // Xt_j[p,k,p''] = X_mu[p'',k,p], mu = d-1-j.
-    for (int j = 0; j < d - 1; ++j) {
-        const int mu = d - 1 - j;
-        const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
-        double *Rn = ws + offR[j];
-        if (j == 0) {
-            // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
-            CK(gemm(3, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
-        } else {
-            const double *Rc = ws + offR[j - 1];                   // (sp x rho)
-            // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
-            CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
-            // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
-            CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+    {
+        double *T = ws + offTR;
+        for (int j = 0; j < d - 1; ++j) {
+            const int mu = d - 1 - j;
+            const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
+            double *Rn = ws + offR[j];
+            if (j == 0) {
+                // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
+                CK(gemm(3, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
+            } else {
+                const double *Rc = ws + offR[j - 1];                   // (sp x rho)
+                // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
+                CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
+                // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
+                CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+            }
         }
     }
-    // ---- left chain fused with Psi and Omega
-    double *psi = out;
+    // ---- left chain (aux): L_mu and the shared products T_mu = L_{mu-1}^T X_mu
+    for (int mu = 0; mu < d; ++mu) {
+        const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
+        if (mu == 0) {
+            // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
+            CK(gemm(3, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
+            continue;
+        }
+        const int64_t lfull = lt[mu];
+        const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
+        double *T = ws + offT[mu];
+        // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
+        CK(gemm(0, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
+        if (mu < d - 1)
+            // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
+            CK(gemm(1, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1, ws + offL[mu],
+                    lt[mu + 1], 1, 0, aux));
+    }
+    // both chains are needed from here on, on both streams
+    CK(ttsk_stream_wait(stream, aux));
+    CK(ttsk_stream_wait(aux, stream));
+
+    // ---- Psi and Omega, dealt over the two streams
     std::vector<double *> psi_at(d), om_at(d - 1);
     {
         double *p = out;
@@ -162,43 +195,37 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
             p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
         }
     }
-    (void)psi;
     for (int mu = 0; mu < d; ++mu) {
-        const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
+        const int64_t sp = s[mu + 1], nn = n[mu];
+        const int q = (mu & 1) ? aux : stream;
+        hipStream_t stq = stream_of(q);
         // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
         const int jr = d - 2 - mu;
         const double *Rm = mu < d - 1 ? ws + offR[jr] + r_lo[jr] : nullptr;
         const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
         if (mu == 0) {
             // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c]
-            CK(gemm(2, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, stream));
-            // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
-            CK(gemm(3, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, stream));
+            CK(gemm(2, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, q));
         } else {
-            const int64_t lfull = lt[mu], l = l_hi[mu - 1] - l_lo[mu - 1];
-            const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
-            // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
-            CK(gemm(0, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, stream));
-            const double *Ts = T + l_lo[mu - 1] * nn * sp;          // rows of the rank slice
+            const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
+            const double *Ts = ws + offT[mu] + l_lo[mu - 1] * nn * sp;   // rows of the rank slice
             if (mu < d - 1) {
                 // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
-                CK(gemm(2, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, stream));
-                // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
-                CK(gemm(1, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1,
-                        ws + offL[mu], lt[mu + 1], 1, 0, stream));
+                CK(gemm(2, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, q));
             } else {
                 // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
-                if (accumulate) CK(ttsk_axpby(psi_at[mu], Ts, 1.0, 1.0, (size_t)(l * nn), stream));
-                else TTSK_HIP(hipMemcpyAsync(psi_at[mu], Ts, (size_t)(l * nn) * 8, hipMemcpyDeviceToDevice, st));
+                if (accumulate) CK(ttsk_axpby(psi_at[mu], Ts, 1.0, 1.0, (size_t)(l * nn), q));
+                else TTSK_HIP(hipMemcpyAsync(psi_at[mu], Ts, (size_t)(l * nn) * 8, hipMemcpyDeviceToDevice, stq));
             }
         }
         if (mu < d - 1) {
             // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]
             const int64_t l = l_hi[mu] - l_lo[mu];
             CK(gemm(3, l, r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1, om_at[mu], r, 1,
-                    accumulate, stream));
+                    accumulate, q));
         }
     }
+    CK(ttsk_stream_wait(stream, aux));   // join
 #undef CK
     return TTSK_OK;
 }
