@@ -191,19 +191,27 @@ def main():
             plan.run(ptrs, out)
         nat.call("ttsk_sync", -1)
         classes = {}
-        names = {0: "chain_gemm1 T=L^T X", 1: "chain_gemm2 split-K", 2: "psi_gemm", 3: "small (Omega, mode 0)"}
-        for c in range(4):
+        # class -> (label, rocprof kernel name of the main contraction kernel at this workload)
+        names = {0: ("right chain GEMM1  T = R^T X^T", "gemm_f64_kernel<1, 4, 7, 1, false, true>"),
+                 1: ("right chain GEMM2  R' = sum T E (split-K)", "gemm_f64_kernel<1, 4, 7, 1, true, false>"),
+                 2: ("left chain GEMM1  T = L^T X", "gemm_f64_kernel<1, 4, 4, 1, false, false>"),
+                 3: ("left chain GEMM2  L' = sum T D (split-K)", "gemm_f64_kernel<4, 1, 1, 4, false, false>"),
+                 4: ("Psi GEMM  Psi = T R", "gemm_f64_kernel<4, 1, 1, 7, true, false>"),
+                 5: ("small products (Omega, first / last mode)", "gemm_f64_kernel<...> (several)")}
+        for c, (label, kname) in names.items():
             n_l, ms, flops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             nat.call("ttsk_prof_read", c, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(flops))
             if n_l.value:
-                classes[names[c]] = dict(launches_per_sketch=n_l.value / reps, avg_us=1e3 * ms.value / n_l.value,
-                                         tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
-                                         share_ms=ms.value / reps)
+                classes[label] = dict(kernel=kname, launches_per_sketch=n_l.value / reps,
+                                      avg_us=1e3 * ms.value / n_l.value,
+                                      gflop_per_launch=flops.value / n_l.value * 1e-9,
+                                      tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
+                                      share_ms=ms.value / reps)
         nat.call("ttsk_prof_enable", 0)
         dom = max(classes, key=lambda k: classes[k]["share_ms"])
         probe = ctypes.c_double()
         nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
-        roofline = dict(bound="mfma", kernel=dom, achieved=classes[dom]["tflops"], peak=PEAK_F64_MFMA_TF,
+        roofline = dict(bound="mfma", kernel=classes[dom]["kernel"], what=dom, achieved=classes[dom]["tflops"], peak=PEAK_F64_MFMA_TF,
                         unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF, traffic=None,
                         avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value,
                         classes=classes,

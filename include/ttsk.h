@@ -120,7 +120,9 @@ int ttsk_prof_enable(int on);
  * 4 independent accumulators per wave, every CU busy): TFLOP/s.  MI355X_MICROARCH.md lists
  * no fp64 MFMA row, so bench.py states this number next to the 78.6 TF/s data-sheet value. */
 int ttsk_mfma_f64_peak_probe(double *tflops);
-/* class 0: chain GEMM1 (T = L^T X), 1: chain GEMM2 (split-K), 2: Psi GEMM, 3: other */
+/* class 0/1: right-chain GEMM1 (T = R^T X^T) / GEMM2 (split-K); 2/3: left-chain GEMM1 / GEMM2;
+ * 4: Psi GEMM; 5: small products (Omega, first mode); 7: untagged ttsk_gemm calls.  Only the main
+ * contraction kernel of each call is bracketed (not the split-K reduce / zero fill). */
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops);
 
 /* ---- hash sampler (the reference's native module) -------------------------

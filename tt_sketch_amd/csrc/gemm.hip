@@ -198,10 +198,13 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
                         span_b * 8 < (1ll << 31);
     GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, fast_ok, kchunk, p.bm, p.bn};
     int rc;
+    const bool prof = prof_on();
+    if (prof) prof_open(st, 2.0 * (double)d.batch * (double)d.M * (double)d.N * (double)K);
     if (ak && bk) rc = launch_gemm_layout<true, true>(g, st);
     else if (ak) rc = launch_gemm_layout<true, false>(g, st);
     else if (bk) rc = launch_gemm_layout<false, true>(g, st);
     else rc = launch_gemm_layout<false, false>(g, st);
+    if (prof) prof_close(st);
     if (rc || !partial) return rc;
     const int64_t total = d.batch * tiles_m * tiles_n * 256;
     int64_t blocks = cdiv(total, 64);

@@ -5,11 +5,27 @@
 
 namespace ttsk {
 
+constexpr int NCLS = 8;
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 static bool g_prof = false;
+static int g_cls = NCLS - 1;
 static std::vector<ProfRec> g_recs;
-static int64_t g_launches[4];
-static double g_ms[4], g_flops[4];
+static int64_t g_launches[NCLS];
+static double g_ms[NCLS], g_flops[NCLS];
+
+// called by ttsk_gemm around its main kernel launch (not the split-K reduce / zero fill)
+bool prof_on() { return g_prof; }
+void prof_open(hipStream_t st, double flops)
+{
+    ProfRec r{};
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, st);
+    r.cls = g_cls;
+    r.flops = flops;
+    g_recs.push_back(r);
+}
+void prof_close(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
 
 static void prof_flush()
 {
@@ -26,7 +42,7 @@ static void prof_flush()
     g_recs.clear();
 }
 
-// C[M,N] (+)= A * B with generic strides; thin wrapper that also does the profiling bracket.
+// C[M,N] (+)= A * B with generic strides; tags the launch with its profiling class.
 static int gemm(int cls, int64_t M, int64_t N, int64_t Ko, int64_t Ki, const double *A, int64_t a_m,
                 int64_t a_ko, int64_t a_ki, const double *B, int64_t b_ko, int64_t b_ki, int64_t b_n,
                 double *C, int64_t c_m, int64_t c_n, int accumulate, int stream)
@@ -37,20 +53,9 @@ static int gemm(int cls, int64_t M, int64_t N, int64_t Ko, int64_t Ki, const dou
     d.b_ko = b_ko; d.b_ki = b_ki; d.b_n = b_n;
     d.c_m = c_m; d.c_n = c_n;
     d.alpha = 1.0; d.accumulate = accumulate; d.split_k = 0;
-    ProfRec r{};
-    hipStream_t st = stream_of(stream);
-    if (g_prof) {
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, st);
-    }
+    g_cls = cls;
     int rc = ttsk_gemm(&d, A, B, C, nullptr, stream);
-    if (g_prof) {
-        (void)hipEventRecord(r.b, st);
-        r.cls = cls;
-        r.flops = 2.0 * (double)M * (double)N * (double)(Ko * Ki);
-        g_recs.push_back(r);
-    }
+    g_cls = NCLS - 1;
     return rc;
 }
 
@@ -66,7 +71,7 @@ int ttsk_prof_enable(int on)
     if (!on) prof_flush();
     else {
         prof_flush();
-        for (int i = 0; i < 4; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_flops[i] = 0; }
+        for (int i = 0; i < NCLS; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_flops[i] = 0; }
     }
     g_prof = on != 0;
     return TTSK_OK;
@@ -74,7 +79,7 @@ int ttsk_prof_enable(int on)
 
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops)
 {
-    TTSK_ARG(cls >= 0 && cls < 4, "ttsk_prof_read: class %d", cls);
+    TTSK_ARG(cls >= 0 && cls < NCLS, "ttsk_prof_read: class %d", cls);
     prof_flush();
     if (launches) *launches = g_launches[cls];
     if (total_ms) *total_ms = g_ms[cls];
@@ -148,7 +153,7 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
             double *Rn = ws + offR[j];
             if (j == 0) {
                 // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
-                CK(gemm(3, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
+                CK(gemm(5, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
             } else {
                 const double *Rc = ws + offR[j - 1];                   // (sp x rho)
                 // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
@@ -163,17 +168,17 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
         if (mu == 0) {
             // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
-            CK(gemm(3, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
+            CK(gemm(5, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
             continue;
         }
         const int64_t lfull = lt[mu];
         const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
         double *T = ws + offT[mu];
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
-        CK(gemm(0, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
+        CK(gemm(2, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
         if (mu < d - 1)
             // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
-            CK(gemm(1, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1, ws + offL[mu],
+            CK(gemm(3, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1, ws + offL[mu],
                     lt[mu + 1], 1, 0, aux));
     }
     // both chains are needed from here on, on both streams
@@ -205,13 +210,13 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
         if (mu == 0) {
             // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c]
-            CK(gemm(2, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, q));
+            CK(gemm(5, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, q));
         } else {
             const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
             const double *Ts = ws + offT[mu] + l_lo[mu - 1] * nn * sp;   // rows of the rank slice
             if (mu < d - 1) {
                 // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
-                CK(gemm(2, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, q));
+                CK(gemm(4, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, q));
             } else {
                 // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
                 if (accumulate) CK(ttsk_axpby(psi_at[mu], Ts, 1.0, 1.0, (size_t)(l * nn), q));
@@ -221,7 +226,7 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         if (mu < d - 1) {
             // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]
             const int64_t l = l_hi[mu] - l_lo[mu];
-            CK(gemm(3, l, r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1, om_at[mu], r, 1,
+            CK(gemm(5, l, r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1, om_at[mu], r, 1,
                     accumulate, q));
         }
     }
