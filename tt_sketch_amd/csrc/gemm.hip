@@ -13,6 +13,7 @@
 // conflict free and the MFMA fragment reads (ds_read_b64) hit 64 distinct banks:
 //   "m-fast": tile[k][m], ld = BM+16 (== 16 mod 32)   "k-fast": tile[m][k], ld = 18 (== 2 mod 32)
 // Split-K over (ko,ki) through gridDim.z with fp64 global atomics.
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 namespace ttsk {
@@ -119,9 +120,22 @@ struct GemmPlan {
 
 static GemmPlan plan_gemm(int64_t M, int64_t N)
 {
+    // Tiles per wave in the skinny families are capped (default 4): smaller workgroups leave room
+    // for 3-4 of them per CU, and co-resident workgroups are what hides the load latency of these
+    // short-K products (one wave per SIMD cannot overlap its own loads with its MFMAs).
+    static int cap = [] {
+        const char *e = getenv("TTSK_MAX_TILES");
+        int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
     GemmPlan p;
-    if (M <= 128 && M <= N) { p.family = 1; p.tiles = (int)cdiv(M, 16); p.bm = 16 * p.tiles; p.bn = 64; }
-    else if (N <= 128) { p.family = 2; p.tiles = (int)cdiv(N, 16); p.bm = 64; p.bn = 16 * p.tiles; }
+    auto split = [&](int64_t X) {            // tiles per wave so that rows*tiles covers ceil(X/16) evenly
+        const int need = (int)cdiv(X, 16);
+        const int rows = (int)cdiv(need, cap);
+        return (int)cdiv(need, rows);
+    };
+    if (M <= 128 && M <= N) { p.family = 1; p.tiles = split(M); p.bm = 16 * p.tiles; p.bn = 64; }
+    else if (N <= 128) { p.family = 2; p.tiles = split(N); p.bm = 64; p.bn = 16 * p.tiles; }
     else { p.family = 0; p.tiles = 2; p.bm = 64; p.bn = 64; }
     return p;
 }
@@ -192,11 +206,16 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     // 16-byte loads additionally need whole pairs inside the extents
     if (ak ? (K & 1) : (d.M & 1)) avec = 0;
     if (bk ? (K & 1) : (d.N & 1)) bvec = 0;
-    // the fast staging path addresses a tile as uniform base + 32-bit byte offset
-    const int64_t span_a = (int64_t)p.bm * d.a_m + BK * d.a_ki, span_b = (int64_t)p.bn * d.b_n + BK * d.b_ki;
-    const int fast_ok = d.a_m >= 0 && d.b_n >= 0 && d.a_ki >= 0 && d.b_ki >= 0 && span_a * 8 < (1ll << 31) &&
-                        span_b * 8 < (1ll << 31);
-    GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, fast_ok, kchunk, p.bm, p.bn};
+    // The fast staging path addresses a tile through a buffer resource: 32-bit byte offsets from the
+    // workgroup's first row / column, K offset in a scalar register.
+    const int64_t a_extent = (d.M - 1) * d.a_m + (d.Ko - 1) * d.a_ko + (d.Ki - 1) * d.a_ki + 1;
+    const int64_t b_extent = (d.N - 1) * d.b_n + (d.Ko - 1) * d.b_ko + (d.Ki - 1) * d.b_ki + 1;
+    const int64_t span_a = (int64_t)p.bm * d.a_m + d.Ko * d.a_ko + (d.Ki + BK) * d.a_ki;
+    const int64_t span_b = (int64_t)p.bn * d.b_n + d.Ko * d.b_ko + (d.Ki + BK) * d.b_ki;
+    const int fast_ok = d.a_m >= 0 && d.b_n >= 0 && d.a_ki >= 0 && d.b_ki >= 0 && d.a_ko >= 0 && d.b_ko >= 0 &&
+                        span_a * 8 < (1ll << 31) && span_b * 8 < (1ll << 31);
+    GemmLaunch g{d, A, B, k_scale, C, partial, p.family, p.tiles, splits, avec, bvec, fast_ok, kchunk, p.bm, p.bn,
+                 a_extent, b_extent};
     int rc;
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * (double)d.batch * (double)d.M * (double)d.N * (double)K);

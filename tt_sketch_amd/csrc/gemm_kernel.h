@@ -1,9 +1,18 @@
 // fp64 MFMA contraction kernel template (see gemm.hip for the host side).
 #pragma once
 #include <cstdint>
+#include <type_traits>
 #include "common.h"
 
 namespace ttsk {
+
+// in-kernel cycle stamps for the diagnostic build in scratch/ (no-ops in the library)
+#ifdef TTSK_STAMPS
+__device__ long long g_stamps[256];
+#define TTSK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TTSK_STAMP(i) do { } while (0)
+#endif
 
 constexpr int BK = 32;        // K depth of one staged tile
 constexpr int LDKF = BK + 2;  // "k-fast" LDS layout tile[x][k], ld == 2 (mod 32)
@@ -54,94 +63,103 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
 
 // One operand tile: global -> registers -> LDS.  X = the non-contracted index (m or n).
 //
-// Fast path (interior K-tiles, offsets below 2 GB): every pair of the tile is one
-// `global_load_dwordx4 v, v_off, s[base]` -- a wave-uniform base pointer that the scalar unit
-// advances per K-tile plus a per-thread 32-bit byte offset computed once in init().  No vector
-// ALU work per load, which matters because the fp64 MFMA rate is so low on this part that a
-// few VALU instructions per MFMA already set the pace (measured: 4.3 VALU per MFMA cost 60 %).
-// Row / column overhang is handled by clamping the offset in init() and zeroing at the LDS
-// store.  Slow path (K tail, tiles that straddle two `ko` slices, > 2 GB strides): branch-free
-// clamped loads with full index arithmetic.
+// Loads are `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a wave-uniform buffer resource
+// for the operand (base rebased to the workgroup's first row/column, num_records = what is left of
+// the operand, so anything past its end reads as 0 instead of faulting), a per-thread 32-bit byte
+// offset fixed at kernel start and a scalar offset that the SALU advances per K-tile.  No vector
+// ALU work and no branches per load; with one wave per SIMD every VALU instruction costs 4-8
+// cycles that the fp64 matrix pipe (16 cycles per MFMA) cannot hide.
+// Rows / columns beyond M / N read valid-or-zero data and only pollute accumulator rows /
+// columns that are never stored.  Only the contracted index needs exact zeros: K-tail tiles
+// (and tiles straddling two `ko` slices) go through load_adj + a masked LDS store.
+// The 256 threads x NE2 pairs cover the (16 T W) x 32 tile exactly: no per-element validity.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const double *base, int64_t bytes)
+{
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ double2 ld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return *reinterpret_cast<double2 *>(&v);
+}
+__device__ __forceinline__ double ld8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return *reinterpret_cast<double *>(&v);
+}
+
 template <bool KF, int NE2>
 struct Stager {
-    double2 r[NE2];
-    uint32_t goff[NE2];  // byte offset of the pair from the tile base (x clamped), K-tile relative
-    int lds[NE2];        // LDS offset [15:0] | k [21:16] | pair-element-1 invalid [28] | element-0 invalid [29];
-                         // negative: pair not in the tile
-    __device__ __forceinline__ void init(int bx, int ld, int tid, int64_t x0, int64_t X, int64_t xs,
-                                         int64_t s_ki)
+    uint32_t goff[NE2];  // byte offset of pair e from the tile origin (x0, k-tile start)
+    uint32_t lds[NE2];   // LDS byte offset of pair e
+    template <int BX>
+    __device__ __forceinline__ void init(int ld, int tid, uint32_t xs8, uint32_t ski8)
     {
-        const int half = KF ? BK / 2 : bx / 2;
+        constexpr int half = KF ? BK / 2 : BX / 2;
 #pragma unroll
         for (int e = 0; e < NE2; ++e) {
             const int idx = tid + 256 * e;
             int x, k;
-            if (KF) { k = 2 * (idx % (BK / 2)); x = idx / (BK / 2); }
+            if (KF) { k = 2 * (idx % half); x = idx / half; }
             else    { x = 2 * (idx % half); k = idx / half; }
-            if (x < bx && k < BK) {
-                const int64_t gx = x0 + x;
-                const int x1 = KF ? x : x + 1;
-                const bool in0 = gx < X, in1 = x0 + x1 < X;
-                // clamp so that even a masked-out pair reads valid memory
-                int64_t cx = gx;
-                if (gx >= X) {
-                    cx = KF ? X - 1 : X - 2;      // a whole pair that exists (16-byte loads need X even)
-                    if (cx < x0) cx = x0;
-                }
-                goff[e] = (uint32_t)(((cx - x0) * xs + (int64_t)k * s_ki) * 8);
-                lds[e] = (KF ? x * LDKF + k : k * ld + x) | (k << 16) | (in0 ? 0 : 0x20000000) | (in1 ? 0 : 0x10000000);
-            } else {
-                goff[e] = 0;
-                lds[e] = -1;
-            }
+            goff[e] = (uint32_t)x * xs8 + (uint32_t)k * ski8;
+            lds[e] = (uint32_t)(KF ? x * LDKF + k : k * ld + x) * 8u;
         }
     }
-    // Fast path: base = address of tile element (x0, k0).  second_off: byte distance between the two
-    // elements of a pair when 16-byte loads are not possible.
-    __device__ __forceinline__ void load_fast(const char *__restrict__ base, bool vec, uint32_t second_off)
+    template <int BX>
+    __device__ __forceinline__ int kk(int e, int tid) const
+    {
+        constexpr int half = KF ? BK / 2 : BX / 2;
+        const int idx = tid + 256 * e;
+        return KF ? 2 * (idx % half) : idx / half;
+    }
+    __device__ __forceinline__ void load_fast(double2 (&r)[NE2], __amdgpu_buffer_rsrc_t rs, uint32_t soff, bool vec,
+                                              uint32_t second_off) const
     {
         if (vec) {
 #pragma unroll
-            for (int e = 0; e < NE2; ++e) r[e] = *reinterpret_cast<const double2 *>(base + goff[e]);
+            for (int e = 0; e < NE2; ++e) r[e] = ld16(rs, goff[e], soff);
         } else {
 #pragma unroll
             for (int e = 0; e < NE2; ++e) {
-                r[e].x = *reinterpret_cast<const double *>(base + goff[e]);
-                r[e].y = *reinterpret_cast<const double *>(base + goff[e] + ((lds[e] & 0x10000000) ? 0u : second_off));
+                r[e].x = ld8(rs, goff[e], soff);
+                r[e].y = ld8(rs, goff[e] + second_off, soff);
             }
         }
     }
-    // K tail (kcount < BK valid k) and tiles that straddle two `ko` slices (ki0 + k wraps at Ki):
-    // same loads with a per-element K adjustment; scalar 8-byte loads, the pair may split.
-    __device__ __forceinline__ void load_adj(const char *__restrict__ base, uint32_t second_off, int kcount,
-                                             int64_t ki0, int64_t Ki, int64_t s_ki, int64_t s_ko)
+    // tiles that straddle two `ko` slices (ki0 + k wraps at Ki): per-element K adjustment, 8-byte loads
+    template <int BX>
+    __device__ __forceinline__ void load_adj(double2 (&r)[NE2], __amdgpu_buffer_rsrc_t rs, uint32_t soff,
+                                             uint32_t second_off, int64_t ki0, int64_t Ki, int64_t wrap_bytes,
+                                             int tid) const
     {
-        const int64_t wrap = (s_ko - Ki * s_ki) * 8;
 #pragma unroll
         for (int e = 0; e < NE2; ++e) {
-            const int k = (lds[e] >> 16) & 63;
-            const int k1 = KF ? k + 1 : k;
-            const int c0 = k < kcount ? k : kcount - 1, c1 = k1 < kcount ? k1 : kcount - 1;
-            // goff holds x-part + k*s_ki*8; re-base the k part on the clamped / wrapped index
-            const int64_t o0 = (int64_t)goff[e] + (int64_t)(c0 - k) * s_ki * 8 + ((ki0 + c0 >= Ki) ? wrap : 0);
-            int64_t o1 = (int64_t)goff[e] + (int64_t)(c1 - k) * s_ki * 8 + ((ki0 + c1 >= Ki) ? wrap : 0);
-            if (!KF) o1 += (lds[e] & 0x10000000) ? 0 : second_off;
-            r[e].x = *reinterpret_cast<const double *>(base + o0);
-            r[e].y = *reinterpret_cast<const double *>(base + o1);
+            const int k = kk<BX>(e, tid), k1 = KF ? k + 1 : k;
+            const uint32_t w0 = (ki0 + k >= Ki) ? (uint32_t)wrap_bytes : 0u;
+            const uint32_t w1 = (ki0 + k1 >= Ki) ? (uint32_t)wrap_bytes : 0u;
+            r[e].x = ld8(rs, goff[e] + w0, soff);
+            r[e].y = ld8(rs, goff[e] + second_off + w1, soff);
         }
     }
-    __device__ __forceinline__ void store(double *S, bool edge, int kcount) const
+    template <int BX>
+    __device__ __forceinline__ void store(const double2 (&r)[NE2], char *S, bool mask_k, int kcount, int tid) const
     {
+        if (!mask_k) {
 #pragma unroll
-        for (int e = 0; e < NE2; ++e) {
-            if (lds[e] >= 0) {
+            for (int e = 0; e < NE2; ++e) *reinterpret_cast<double2 *>(S + lds[e]) = r[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE2; ++e) {
+                const int k = kk<BX>(e, tid), k1 = KF ? k + 1 : k;
                 double2 v = r[e];
-                if (edge) {
-                    const int k = (lds[e] >> 16) & 63;
-                    if ((lds[e] & 0x20000000) || k >= kcount) v.x = 0.0;
-                    if ((lds[e] & 0x10000000) || (KF ? k + 1 : k) >= kcount) v.y = 0.0;
-                }
-                *reinterpret_cast<double2 *>(S + (lds[e] & 0xFFFF)) = v;
+                if (k >= kcount) v.x = 0.0;
+                if (k1 >= kcount) v.y = 0.0;
+                *reinterpret_cast<double2 *>(S + lds[e]) = v;
             }
         }
     }
@@ -177,9 +195,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
                                                        const double *__restrict__ B, double *__restrict__ C,
                                                        const double *__restrict__ kscale, int splits,
                                                        int64_t kchunk, double *__restrict__ partial,
-                                                       int avec, int bvec, int fast_ok)
+                                                       int avec, int bvec, int fast_ok, int64_t a_extent,
+                                                       int64_t b_extent)
 {
     static_assert(WM * WN == 4, "256 threads");
+    TTSK_STAMP(0);
     constexpr int tm = TMX, tn = TNX;
     constexpr bool ROTA = WM > WN;    // skinny-N family: one A tile per wave, rotate it
     constexpr int NEA = WM * TMX, NEB = WN * TNX;  // double2 per thread: 16 t W * 32 / 256 / 2
@@ -202,7 +222,6 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
     const double *Bb = B + b * d.b_b;
     const KMap ka{d.Ko, d.Ki, d.a_ko, d.a_ki};
     const KMap kb{d.Ko, d.Ki, d.b_ko, d.b_ki};
-    const bool edge_a = m0 + bm > d.M, edge_b = n0 + bn > d.N;
 
     double acc[TMX][TNX][4];
 #pragma unroll
@@ -214,14 +233,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
 
     Stager<AKF, NEA> sa;
     Stager<BKF, NEB> sb;
-    sa.init(bm, lda, tid, m0, d.M, d.a_m, d.a_ki);
-    sb.init(bn, ldb, tid, n0, d.N, d.b_n, d.b_ki);
+    sa.template init<bm>(lda, tid, (uint32_t)(d.a_m * 8), (uint32_t)(d.a_ki * 8));
+    sb.template init<bn>(ldb, tid, (uint32_t)(d.b_n * 8), (uint32_t)(d.b_ki * 8));
+    TTSK_STAMP(1);
     const uint32_t a2 = (uint32_t)((AKF ? d.a_ki : d.a_m) * 8), b2 = (uint32_t)((BKF ? d.b_ki : d.b_n) * 8);
-    const char *a_base = reinterpret_cast<const char *>(Ab + m0 * d.a_m);
-    const char *b_base = reinterpret_cast<const char *>(Bb + n0 * d.b_n);
+    // buffer resources rebased to this workgroup's first row / column; what lies past the operand reads 0
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(Ab + m0 * d.a_m, (a_extent - m0 * d.a_m) * 8);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(Bb + n0 * d.b_n, (b_extent - n0 * d.b_n) * 8);
+    char *Asb = reinterpret_cast<char *>(As), *Bsb = reinterpret_cast<char *>(Bs);
 
-    // Staging modes per K-tile: 2 = pure fast path, 1 = fast path with K adjustment (tail /
-    // ko-straddle), 0 = rolled generic fill (k_scale, tiny Ki, offsets beyond 32 bits).
+    // Staging modes per K-tile: 2 = plain, 1 = K adjustment (tail / ko-straddle), 0 = rolled generic
+    // fill (k_scale, tiny Ki, offsets beyond 32 bits).
     auto mode_of = [&](int64_t k0) -> int {
         if (!fast_ok || kscale) return 0;
         const bool full = k0 + BK <= kend;
@@ -230,42 +252,50 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
         const int64_t ki0 = k0 % d.Ki;
         return (full && ki0 + BK <= d.Ki) ? 2 : 1;
     };
-    auto prefetch = [&](int64_t k0, int mode) {
+    // NST K-tiles in flight in registers: with K of order 100 a workgroup only has 3-4 tiles, and
+    // issuing their loads back to back (instead of one tile per iteration) removes the
+    // per-iteration memory round trip of these short-K products.
+    constexpr int NST = 3;
+    double2 ra[NST][NEA], rb[NST][NEB];
+    auto prefetch = [&](double2 (&xa)[NEA], double2 (&xb)[NEB], int64_t k0, int mode) {
         int64_t ko0 = 0, ki0 = k0;
         if (d.Ko != 1) { ko0 = k0 / d.Ki; ki0 = k0 - ko0 * d.Ki; }
-        const char *pa = a_base + (ko0 * d.a_ko + ki0 * d.a_ki) * 8;
-        const char *pb = b_base + (ko0 * d.b_ko + ki0 * d.b_ki) * 8;
-        if (mode == 2) {
-            sa.load_fast(pa, avec, a2);
-            sb.load_fast(pb, bvec, b2);
+        const uint32_t sa_off = (uint32_t)((ko0 * d.a_ko + ki0 * d.a_ki) * 8);
+        const uint32_t sb_off = (uint32_t)((ko0 * d.b_ko + ki0 * d.b_ki) * 8);
+        if (mode == 2 || d.Ko == 1) {
+            sa.load_fast(xa, rsa, sa_off, avec, a2);
+            sb.load_fast(xb, rsb, sb_off, bvec, b2);
         } else {
-            const int kc = (int)((kend - k0 < BK) ? kend - k0 : BK);
-            const int64_t Ki = d.Ko == 1 ? (int64_t)1 << 60 : d.Ki;
-            sa.load_adj(pa, a2, kc, ki0, Ki, d.a_ki, d.a_ko);
-            sb.load_adj(pb, b2, kc, ki0, Ki, d.b_ki, d.b_ko);
+            sa.template load_adj<bm>(xa, rsa, sa_off, a2, ki0, d.Ki, (d.a_ko - d.Ki * d.a_ki) * 8, tid);
+            sb.template load_adj<bn>(xb, rsb, sb_off, b2, ki0, d.Ki, (d.b_ko - d.Ki * d.b_ki) * 8, tid);
         }
     };
 
     const int fi = lane >> 4, fj = lane & 15;
-    int cur_mode = kbeg < kend ? mode_of(kbeg) : 0;
-    if (cur_mode) prefetch(kbeg, cur_mode);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    // one K-tile: registers (slot P) -> LDS, refill the slot NST tiles ahead, MFMAs
+    auto step = [&](auto SLOT, int64_t k0, int &mode) {
+        constexpr int P = decltype(SLOT)::value;
         const int kcount = (int)((kend - k0 < BK) ? kend - k0 : BK);
+        const int sb_ = 8 + 8 * (int)((k0 - kbeg) / BK);
+        TTSK_STAMP(sb_);
         __syncthreads();
-        if (cur_mode) {
-            sa.store(As, edge_a || cur_mode == 1, kcount);
-            sb.store(Bs, edge_b || cur_mode == 1, kcount);
+        TTSK_STAMP(sb_ + 1);
+        if (mode) {
+            sa.template store<bm>(ra[P], Asb, mode == 1, kcount, tid);
+            sb.template store<bn>(rb[P], Bsb, mode == 1, kcount, tid);
         } else {
             slow_fill<AKF>(As, Ab, d.a_m, ka, m0, d.M, k0, kend, bm, lda, kscale, tid);
             slow_fill<BKF>(Bs, Bb, d.b_n, kb, n0, d.N, k0, kend, bn, ldb, nullptr, tid);
         }
+        TTSK_STAMP(sb_ + 2);
         __syncthreads();
-        cur_mode = k0 + BK < kend ? mode_of(k0 + BK) : 0;
-        if (cur_mode) prefetch(k0 + BK, cur_mode);
-#pragma unroll
-        for (int ks = 0; ks < BK; ks += 4) {
-            if (ks >= kcount) break;
-            double af[TMX], bf[TNX];
+        TTSK_STAMP(sb_ + 3);
+        mode = k0 + NST * BK < kend ? mode_of(k0 + NST * BK) : 0;
+        if (mode) prefetch(ra[P], rb[P], k0 + NST * BK, mode);
+        TTSK_STAMP(sb_ + 4);
+        // software-pipelined k-steps: the LDS fragment reads (and the DPP rotation) of step ks+4
+        // are issued before the MFMAs of step ks, so one wave per SIMD keeps its matrix pipe busy
+        auto frag = [&](int ks, double (&af)[TMX], double (&bf)[TNX]) {
 #pragma unroll
             for (int i = 0; i < TMX; ++i) {
                 const int x = (wr * tm + i) * 16 + fj;
@@ -276,30 +306,53 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const d
                 const int x = (wc * tn + j) * 16 + fj;
                 bf[j] = Bs[BKF ? x * LDKF + ks + fi : (ks + fi) * ldb + x];
             }
-            if (ROTA) {
+        };
+        constexpr int NR = ROTA ? TMX : TNX;          // tiles of the rotated operand
+        auto rotate = [&](const double (&af)[TMX], const double (&bf)[TNX], double (&rr)[NR][4]) {
 #pragma unroll
-                for (int i = 0; i < TMX; ++i) {
-                    double ar[4];
-                    rot4(af[i], ar);
+            for (int q = 0; q < NR; ++q) rot4(ROTA ? af[q] : bf[q], rr[q]);
+        };
+        auto mma = [&](const double (&af)[TMX], const double (&bf)[TNX], const double (&rr)[NR][4]) {
 #pragma unroll
-                    for (int j = 0; j < TNX; ++j)
+            for (int i = 0; i < TMX; ++i)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(ar[t], bf[j], acc[i][j][t]);
-                }
-            } else {
+                for (int j = 0; j < TNX; ++j)
 #pragma unroll
-                for (int j = 0; j < TNX; ++j) {
-                    double br[4];
-                    rot4(bf[j], br);
+                    for (int t = 0; t < 4; ++t)
+                        acc[i][j][t] = ROTA ? mfma4(rr[i][t], bf[j], acc[i][j][t])
+                                            : mfma4(af[i], rr[j][t], acc[i][j][t]);
+        };
+        double af0[TMX], bf0[TNX], af1[TMX], bf1[TNX], r0[NR][4], r1[NR][4];
+        frag(0, af0, bf0);
+        rotate(af0, bf0, r0);
 #pragma unroll
-                    for (int i = 0; i < TMX; ++i)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[i][j][t] = mfma4(af[i], br[t], acc[i][j][t]);
-                }
-            }
+        for (int ks = 0; ks < BK; ks += 8) {
+            if (ks >= kcount) break;
+            const bool more1 = ks + 4 < kcount, more2 = ks + 8 < kcount;
+            if (more1) frag(ks + 4, af1, bf1);
+            mma(af0, bf0, r0);
+            if (!more1) break;
+            rotate(af1, bf1, r1);
+            if (more2 && ks + 8 < BK) frag(ks + 8, af0, bf0);
+            mma(af1, bf1, r1);
+            if (more2 && ks + 8 < BK) rotate(af0, bf0, r0);
         }
+        TTSK_STAMP(sb_ + 5);
+    };
+    int modes[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) modes[q] = kbeg + q * BK < kend ? mode_of(kbeg + q * BK) : 0;
+    if (modes[0]) prefetch(ra[0], rb[0], kbeg, modes[0]);
+    if (modes[1]) prefetch(ra[1], rb[1], kbeg + BK, modes[1]);
+    if (modes[2]) prefetch(ra[2], rb[2], kbeg + 2 * BK, modes[2]);
+    TTSK_STAMP(2);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += NST * BK) {
+        step(std::integral_constant<int, 0>{}, k0, modes[0]);
+        if (k0 + BK < kend) step(std::integral_constant<int, 1>{}, k0 + BK, modes[1]);
+        if (k0 + 2 * BK < kend) step(std::integral_constant<int, 2>{}, k0 + 2 * BK, modes[2]);
     }
 
+    TTSK_STAMP(3);
     if (partial) {
         // split-K: every wave dumps its accumulators as they sit in registers (64 contiguous
         // doubles per store instruction); splitk_reduce_kernel undoes the lane permutation.
@@ -347,6 +400,7 @@ struct GemmLaunch {
     int splits, avec, bvec, fast_ok;
     int64_t kchunk;
     int bm, bn;
+    int64_t a_extent, b_extent;   // elements from the (per-batch) operand base to its last element + 1
 };
 template <bool AKF, bool BKF> int launch_gemm_layout(const GemmLaunch &g, hipStream_t st);
 
@@ -357,7 +411,7 @@ static int launch_one(const GemmLaunch &g, hipStream_t st)
     dim3 grid((unsigned)cdiv(g.d.N, bn), (unsigned)cdiv(g.d.M, bm), (unsigned)(g.d.batch * g.splits));
     const size_t lds = 8 * (size_t)((AKF ? bm * LDKF : BK * ldmf(bm)) + (BKF ? bn * LDKF : BK * ldmf(bn)));
     hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, TMX, TNX, AKF, BKF>), grid, dim3(256), lds, st, g.d, g.A, g.B, g.C,
-                       g.ks, g.splits, g.kchunk, g.partial, g.avec, g.bvec, g.fast_ok);
+                       g.ks, g.splits, g.kchunk, g.partial, g.avec, g.bvec, g.fast_ok, g.a_extent, g.b_extent);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
