@@ -342,3 +342,24 @@ def test_one_call_tt_path_matches_generic_and_oracle(tsa):
         oP, oO = orc.general_sketch(data[0], data[1], ld, rd, "streaming")
         for a, b, c in zip(fused[0] + fused[1], gen[0] + gen[1], oP + oO):
             assert rel(a.get(), c) < TOL and rel(b.get(), c) < TOL
+
+
+def test_fused_step_kernel_opt_in(tsa, monkeypatch):
+    """The per-mode fused chain-step kernel (csrc/tt_step.hip, opt-in) gives the same sketch."""
+    from tt_sketch_amd import tt_fused
+    from tests.gpu_build import make_drm, make_tensor
+    rng = np.random.default_rng(12)
+    for shape, s, lr, rr in (((9, 12, 7, 10, 8), (3, 6, 5, 4), (4, 7, 6, 5), (6, 9, 8, 7)),
+                             ((20, 33, 18, 25), (40, 70, 35), (30, 50, 20), (45, 100, 60))):
+        cores = orc.random_tt(shape, s, rng)
+        ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
+        if len(shape) == 5:
+            ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)
+            rd.rank_min, rd.rank_max = (0, 3, 1, 2), (5, 8, 9, 6)
+        oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
+        monkeypatch.setenv("TTSK_FUSED_STEP", "1")
+        fused = tt_fused.try_stream_sketch(make_tensor("tt", cores), make_drm(ld), make_drm(rd),
+                                           tsa.SketchMethod.streaming)
+        monkeypatch.delenv("TTSK_FUSED_STEP")
+        for a, c in zip(fused[0] + fused[1], oP + oO):
+            assert rel(a.get(), c) < TOL

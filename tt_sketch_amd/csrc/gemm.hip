@@ -140,6 +140,18 @@ static GemmPlan plan_gemm(int64_t M, int64_t N)
     return p;
 }
 
+int launch_splitk_reduce(const ttsk_gemm_desc &d, const double *partial, double *C, int splits, int64_t tiles_m,
+                         int64_t tiles_n, int rota, hipStream_t st)
+{
+    const int64_t total = d.batch * tiles_m * tiles_n * 256;
+    int64_t blocks = cdiv(total, 64);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, partial, C, splits,
+                       tiles_m, tiles_n, rota);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
 static bool even(int64_t v) { return (v & 1) == 0; }
 
 }  // namespace ttsk
@@ -225,13 +237,7 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     else rc = launch_gemm_layout<false, false>(g, st);
     if (prof) prof_close(st);
     if (rc || !partial) return rc;
-    const int64_t total = d.batch * tiles_m * tiles_n * 256;
-    int64_t blocks = cdiv(total, 64);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, partial, C, splits,
-                       tiles_m, tiles_n, p.family == 2 ? 1 : 0);
-    TTSK_LAUNCH_CHECK();
-    return TTSK_OK;
+    return launch_splitk_reduce(d, partial, C, splits, tiles_m, tiles_n, p.family == 2 ? 1 : 0, st);
 }
 
 int ttsk_mfma_f64_peak_probe(double *tflops)

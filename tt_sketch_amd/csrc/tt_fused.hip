@@ -1,10 +1,13 @@
 // TT input x TT DRMs: the whole streaming sketch (both chains, Omega, Psi) as one C call.
 // See include/ttsk.h (ttsk_tt_sketch) for the contract and the reference lines it replaces.
+#include <cstdlib>
 #include <vector>
 #include "common.h"
+#include "tt_step.h"
 
 namespace ttsk {
 
+constexpr int SMAX_ROWS = 112;   // rows a fused step addresses in an X slab (tt_step.hip SMAX)
 constexpr int NCLS = 8;
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 static bool g_prof = false;
@@ -141,6 +144,97 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
     if (!ws) return TTSK_ERR_HIP;
     int rc;
 #define CK(x) do { rc = (x); if (rc) return rc; } while (0)
+    // ---- fused schedule: every interior chain step is ONE kernel (tt_step.hip) + the slab sum.
+    // The left steps carry Psi and therefore need R_mu, which the right chain produces last-to-first:
+    // the right chain runs to completion first, then the left chain; the small products (first /
+    // last mode, Omega) go to the helper stream.
+    // Measured at the bench workload: 42 us per fused step; the sequential right-then-left schedule
+    // it needs totals 0.51 ms per sketch against 0.41 ms for the two-stream GEMM schedule below, so
+    // the fused step is opt-in (TTSK_FUSED_STEP=1) until its MFMA duty improves.
+    const char *fenv = getenv("TTSK_FUSED_STEP");
+    bool fuse = fenv != nullptr && fenv[0] == '1';
+    for (int mu = 1; mu < d - 1 && fuse; ++mu) {
+        const int j = d - 1 - mu;
+        fuse = tt_step_fits(s[mu + 1], s[mu], rt[j], rt[j + 1], 0, 0, (int64_t)SMAX_ROWS * n[mu] * s[mu + 1]) &&
+               tt_step_fits(s[mu], s[mu + 1], lt[mu], lt[mu + 1], r_hi[d - 2 - mu] - r_lo[d - 2 - mu],
+                            l_hi[mu - 1] - l_lo[mu - 1], (int64_t)(s[mu] + 32) * n[mu] * s[mu + 1]);
+    }
+    if (fuse) {
+        std::vector<double *> psi_at(d), om_at(d - 1);
+        {
+            double *p = out;
+            for (int mu = 0; mu < d; ++mu) {
+                int64_t l = mu == 0 ? 1 : l_hi[mu - 1] - l_lo[mu - 1];
+                int64_t r = mu == d - 1 ? 1 : r_hi[d - 2 - mu] - r_lo[d - 2 - mu];
+                psi_at[mu] = p;
+                p += l * n[mu] * r;
+            }
+            for (int mu = 0; mu < d - 1; ++mu) {
+                om_at[mu] = p;
+                p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
+            }
+        }
+        CK(ttsk_stream_wait(aux, stream));   // fork
+        // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q'] on the helper stream (independent of the right chain)
+        CK(gemm(5, s[1], lt[1], 1, n[0], X[0], 1, 0, s[1], DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
+        // right chain
+        for (int j = 0; j < d - 1; ++j) {
+            const int mu = d - 1 - j;
+            const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
+            double *Rn = ws + offR[j];
+            if (j == 0) {
+                CK(gemm(5, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
+                continue;
+            }
+            StepArgs g{};
+            g.s_in = (int)sp; g.s_out = (int)sn; g.rho = (int)rho; g.rhop = (int)rhop; g.r = 0;
+            g.x_k = sp; g.x_a = nn * sp; g.x_b = 1; g.x_extent = sn * nn * sp;
+            g.X = X[mu]; g.Cin = ws + offR[j - 1]; g.ldc = rho; g.c_extent = sp * rho;
+            g.D = DR[j]; g.d_q = nn * rhop; g.d_k = rhop; g.d_extent = rho * nn * rhop;
+            CK(tt_step_launch(true, nn, g, Rn, rhop, stream));
+        }
+        CK(ttsk_stream_wait(stream, aux));   // L_0 ready
+        // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c] and Omega_0 on the helper stream
+        CK(ttsk_stream_wait(aux, stream));   // right chain complete
+        {
+            const int jr = d - 2;
+            const double *Rm = ws + offR[jr] + r_lo[jr];
+            const int64_t ldr = rt[jr + 1], r = r_hi[jr] - r_lo[jr];
+            CK(gemm(5, n[0], r, 1, s[1], X[0], s[1], 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, aux));
+            CK(gemm(5, l_hi[0] - l_lo[0], r, 1, s[1], ws + offL[0] + l_lo[0], 1, 0, lt[1], Rm, 0, ldr, 1, om_at[0],
+                    r, 1, accumulate, aux));
+        }
+        // left chain with Psi
+        for (int mu = 1; mu < d; ++mu) {
+            const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu], lfull = lt[mu];
+            const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
+            const double *Lc = ws + offL[mu - 1];
+            if (mu == d - 1) {
+                // last mode: Psi_{d-1}[q,k,0] = sum_p L[p, lo+q] X[p,k,0]
+                CK(gemm(5, l, nn, 1, sn, Lc + l_lo[mu - 1], 1, 0, lfull, X[mu], 0, nn * sp, 1, psi_at[mu], nn, 1,
+                        accumulate, stream));
+                break;
+            }
+            const int jr = d - 2 - mu;
+            const double *Rm = ws + offR[jr] + r_lo[jr];
+            const int64_t ldr = rt[jr + 1], r = r_hi[jr] - r_lo[jr];
+            StepArgs g{};
+            g.s_in = (int)sn; g.s_out = (int)sp; g.rho = (int)lfull; g.rhop = (int)lt[mu + 1]; g.r = (int)r;
+            g.q_lo = (int)l_lo[mu - 1]; g.q_cnt = (int)l; g.accumulate_psi = accumulate;
+            g.x_k = sp; g.x_a = 1; g.x_b = nn * sp; g.x_extent = sn * nn * sp;
+            g.X = X[mu]; g.Cin = Lc; g.ldc = lfull; g.c_extent = sn * lfull;
+            g.D = DL[mu]; g.d_q = nn * lt[mu + 1]; g.d_k = lt[mu + 1]; g.d_extent = lfull * nn * lt[mu + 1];
+            g.R = Rm; g.ldr = ldr; g.r_extent = (sp - 1) * ldr + r;
+            g.Psi = psi_at[mu]; g.psi_q = nn * r; g.psi_k = r; g.psi_c = 1;
+            CK(tt_step_launch(false, nn, g, ws + offL[mu], lt[mu + 1], stream));
+            // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi] on the helper stream
+            CK(ttsk_stream_wait(aux, stream));
+            CK(gemm(5, l_hi[mu] - l_lo[mu], r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1,
+                    om_at[mu], r, 1, accumulate, aux));
+        }
+        CK(ttsk_stream_wait(stream, aux));   // join
+        return TTSK_OK;
+    }
     CK(ttsk_stream_wait(aux, stream));   // fork
 
     // ---- right chain (stream): walks modes d-1, ..., 1 on the transposed tensor (views only).
