@@ -103,7 +103,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--graph", type=int, default=0, help="replay the step from a hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent sketches in flight (items of the tensor stream are issued on alternating "
+                         "stream pairs); 1 = strictly one after the other")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,18 +142,24 @@ def main():
     left = TensorTrainDRM(L_RANK, shape, False, seed=1, cores=lcores)
     right = TensorTrainDRM(R_RANK, shape, True, seed=2, cores=rcores)
     plan = TTSketchPlan(tt.shape, tt.rank, left, right)
-    out = plan.new_buffer()
+    inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
+    outs = [plan.new_buffer() for _ in range(inflight)]
+    out = outs[0]
     ptrs, keep = plan.core_pointers(tt)
+    counter = [0]
 
     def step_eager():
-        plan.run(ptrs, out)
+        slot = counter[0] % inflight
+        counter[0] += 1
+        plan.run(ptrs, outs[slot], stream=2 * slot)          # stream pair (2 slot, 2 slot + 1)
         if world > 1:
-            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(out.ptr), ctypes.c_size_t(plan.size), 0)
+            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(outs[slot].ptr), ctypes.c_size_t(plan.size), 2 * slot)
 
     graph = ctypes.c_void_p()
-    step_eager()
+    for _ in range(inflight):
+        step_eager()
     nat.call("ttsk_sync", -1)
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and world == 1 and inflight == 1
     if use_graph:
         nat.call("ttsk_graph_begin", 0)
         plan.run(ptrs, out)
@@ -231,10 +240,11 @@ def main():
                       scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                       config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / "
                                            "right rank 100, streaming sketch (both chains, Omega, Psi), "
-                                           "one TT per GPU per step" +
+                                           f"one TT per GPU per step, {inflight} independent sketches in flight" +
                                            ("; partial sketches summed by one RCCL all-reduce" if world > 1 else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
+                                  sketches_in_flight=inflight,
                                   sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
         print(json.dumps(result))

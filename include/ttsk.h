@@ -36,7 +36,7 @@ typedef enum {
     TTSK_ERR_COMM = -4      /* RCCL failure */
 } ttsk_status;
 
-#define TTSK_NUM_STREAMS 4
+#define TTSK_NUM_STREAMS 8
 
 /* ---- runtime ------------------------------------------------------------ */
 int ttsk_init(int device);                    /* selects the device, creates streams; idempotent */

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
 
 TTSK_ERR_ARG = -2
 TTSK_ERR_UNSUPPORTED = -3
-NUM_STREAMS = 4
+NUM_STREAMS = 8
 
 
 class TtskError(RuntimeError):
