@@ -165,11 +165,17 @@ int ttsk_sparse_densedrm_gather(const double *dev_mat, int64_t rank, int64_t col
                                 const int64_t *shape, int m, size_t N, double *dev_out, int stream);
 /* sketch_psi_sparse (sparse_sketch.py:8-36,49-69):
  *   Psi[a, idx[e], c] += val[e] * Lv[e,a] * Rv[e,c]   (Lv/Rv NULL -> rank 1, value 1)
- * Lv (N,l) and Rv (N,r) row-major as produced above; Psi (l,n,r) contiguous, zeroed by caller. */
-int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, size_t N,
+ * Lv (N,l) and Rv (N,r) row-major as produced above; Psi (l,n,r) contiguous, zeroed by caller.
+ * The kernel reduces runs of equal mode index in registers and issues one atomic per run and
+ * output pair; with `dev_perm` = ttsk_sparse_sort_mode's permutation (nonzeros visited in order of
+ * their mode index) that is a segmented reduction.  dev_idx_row == NULL with n == 1 sums over all
+ * nonzeros: sketch_omega_sparse (sparse_sketch.py:39-46), Omega = (L * entries) R^T. */
+int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int64_t *dev_perm, size_t N,
                     const double *dev_Lv, int64_t l, const double *dev_Rv, int64_t r,
                     int64_t n, double *dev_psi, int stream);
-/* sketch_omega_sparse (sparse_sketch.py:39-46) is ttsk_gemm with k_scale = entries. */
+/* stable sort permutation of the nonzeros by one index row (values < n): perm[i] = id of the i-th
+ * nonzero in mode-index order.  Independent of the DRM: computed once per tensor and mode. */
+int ttsk_sparse_sort_mode(const int64_t *dev_idx_row, size_t N, int64_t n, int64_t *dev_perm, int stream);
 
 /* ---- solves ----------------------------------------------------------------
  * right_mul_pinv / left_mul_pinv (utils.py:98-109; SciPy lstsq -> LAPACK gelsd with

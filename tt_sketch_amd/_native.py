@@ -69,7 +69,8 @@ def _bind(lib):
         "ttsk_fill_normal": [P, S, c_uint64, c_double, I],
         "ttsk_sparse_ttdrm_step": [P, c_int64, P, c_int64, c_int64, P, S, P, I],
         "ttsk_sparse_densedrm_gather": [P, c_int64, c_int64, P, c_int64, POINTER(I), POINTER(c_int64), I, S, P, I],
-        "ttsk_sparse_psi": [P, P, S, P, c_int64, P, c_int64, c_int64, P, I],
+        "ttsk_sparse_psi": [P, P, P, S, P, c_int64, P, c_int64, c_int64, P, I],
+        "ttsk_sparse_sort_mode": [P, S, c_int64, P, I],
         "ttsk_pinv": [P, c_int64, c_int64, c_double, P, POINTER(I), I],
         "ttsk_qr_thin": [P, c_int64, c_int64, I],
         "ttsk_comm_unique_id": [P], "ttsk_comm_init": [P, I, I],

@@ -1,5 +1,6 @@
 // Sparse (COO) input kernels: gather-chain for a TT DRM, column gather for a dense
 // Gaussian DRM, and the Psi scatter.  All HBM-bound streaming of (nnz x rank) panels.
+#include <hipcub/hipcub.hpp>
 #include "common.h"
 
 namespace ttsk {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
             for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
                 size_t e = perm ? (size_t)perm[b0 + t] : b0 + t;
                 sV[t] = val[e];
-                sK[t] = idx[e];
+                sK[t] = idx ? idx[e] : 0;
             }
             for (int64_t t = threadIdx.x; t < (int64_t)cnt * l; t += blockDim.x) {
                 int64_t w = t / l, a2 = t - w * l;
@@ -117,6 +118,12 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
         }
         if (live && cur >= 0 && acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
     }
+}
+
+__global__ void iota_kernel(int64_t *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = (int64_t)i;
 }
 
 }  // namespace ttsk
@@ -171,20 +178,45 @@ int ttsk_sparse_densedrm_gather(const double *dev_mat, int64_t rank, int64_t col
     return TTSK_OK;
 }
 
-int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, size_t N, const double *dev_Lv,
-                    int64_t l, const double *dev_Rv, int64_t r, int64_t n, double *dev_psi, int stream)
+int ttsk_sparse_sort_mode(const int64_t *dev_idx_row, size_t N, int64_t n, int64_t *dev_perm, int stream)
 {
     TTSK_STREAM(st, stream);
-    TTSK_ARG(dev_val && dev_idx_row && dev_psi, "ttsk_sparse_psi: NULL argument");
+    TTSK_ARG(dev_idx_row && dev_perm, "ttsk_sparse_sort_mode: NULL argument");
+    if (N == 0) return TTSK_OK;
+    int bits = 1;
+    while ((1ll << bits) < n && bits < 62) ++bits;
+    // scratch: sorted keys (discarded), identity values, cub temp storage
+    size_t temp_bytes = 0;
+    TTSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const int64_t *)nullptr, (int64_t *)nullptr,
+                                                (const int64_t *)nullptr, (int64_t *)nullptr, (int)N, 0, bits, st));
+    char *ws = (char *)scratch(stream, SCRATCH_MISC, 2 * N * 8 + temp_bytes + 256);
+    if (!ws) return TTSK_ERR_HIP;
+    int64_t *keys_out = (int64_t *)ws, *vals_in = (int64_t *)(ws + N * 8);
+    void *temp = ws + 2 * N * 8;
+    TTSK_ARG(N < (1ull << 31), "ttsk_sparse_sort_mode: more than 2^31 nonzeros");
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N, 1u << 16)), dim3(256), 0, st, vals_in, N);
+    TTSK_LAUNCH_CHECK();
+    TTSK_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, dev_idx_row, keys_out, vals_in, dev_perm, (int)N, 0,
+                                                bits, st));
+    return TTSK_OK;
+}
+
+int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int64_t *dev_perm, size_t N,
+                    const double *dev_Lv, int64_t l, const double *dev_Rv, int64_t r, int64_t n, double *dev_psi,
+                    int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_val && dev_psi, "ttsk_sparse_psi: NULL argument");
     TTSK_ARG(l >= 1 && r >= 1 && n >= 1, "ttsk_sparse_psi: bad shape");
+    TTSK_ARG(dev_idx_row || n == 1, "ttsk_sparse_psi: a NULL index row means a single slice (n = 1)");
     if (N == 0) return TTSK_OK;
     const size_t lds = (size_t)64 * (l + r + 2) * 8;
     TTSK_ARG(lds <= 64 * 1024, "ttsk_sparse_psi: l + r = %lld too large for the staging buffer",
              (long long)(l + r));
-    size_t chunk = 2048;
+    size_t chunk = 4096;
     size_t blocks = (N + chunk - 1) / chunk;
-    hipLaunchKernelGGL(sparse_psi_kernel, dim3((unsigned)blocks), dim3(256), lds, st, dev_val, dev_idx_row,
-                       (const int64_t *)nullptr, N, dev_Lv, l, dev_Rv, r, n, dev_psi, chunk);
+    hipLaunchKernelGGL(sparse_psi_kernel, dim3((unsigned)blocks), dim3(256), lds, st, dev_val, dev_idx_row, dev_perm,
+                       N, dev_Lv, l, dev_Rv, r, n, dev_psi, chunk);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

@@ -188,7 +188,7 @@ class SparseTensor(Tensor):
             # rows are stored in the order of the *first* upload; later views permute
             inv = np.argsort(self._order)
             self._dev = (DevArray.from_host(idx[inv], dtype=np.int64),
-                         DevArray.from_host(np.asarray(self.entries, dtype=np.float64)))
+                         DevArray.from_host(np.asarray(self.entries, dtype=np.float64)), {})
         return self._dev
 
     def prepare_device(self) -> None:
@@ -200,6 +200,21 @@ class SparseTensor(Tensor):
 
     def dev_entries(self) -> DevArray:
         return self._upload()[1]
+
+    def dev_mode_perm(self, mu: int) -> DevArray:
+        """Permutation that visits the nonzeros in order of their (logical) mode-``mu`` index; sorted
+        once per tensor and mode on the device and shared with ``.T`` views."""
+        import ctypes
+        from . import _native as nat
+        idx = self._upload()[0]
+        phys = self._order[mu]
+        cache = self._dev[2]
+        if phys not in cache:
+            perm = DevArray.empty((self.nnz,), dtype=np.int64)
+            nat.call("ttsk_sparse_sort_mode", ctypes.c_void_p(idx.ptr + phys * self.nnz * 8),
+                     ctypes.c_size_t(self.nnz), int(self.shape[mu]), ctypes.c_void_p(perm.ptr), 0)
+            cache[phys] = perm
+        return cache[phys]
 
     @property
     def dev_row_order(self) -> Tuple[int, ...]:
