@@ -59,6 +59,19 @@ def algorithmic_flops(shape, s, l, r):
     return dict(left=left, right=right, omega=omega, psi=psi, total=left + right + omega + psi)
 
 
+def load_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_traffic.json, written by profiles/collect_traffic.py: FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte streaming reads on gfx950, plus WRITE_SIZE)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    entry = table.get(kernel_name)
+    return entry["bytes_per_launch"] if entry else None
+
+
 def make_inputs(seed):
     rng = np.random.default_rng(seed)
     shape = (N_MODE,) * D
@@ -193,35 +206,40 @@ def main():
     result = None
     if rank == 0:
         fl = algorithmic_flops(shape, (S_IN,) * (D - 1), (L_RANK,) * (D - 1), (R_RANK,) * (D - 1))
-        # ---- roofline leg: per-launch device time of each GEMM class (hipEvents on the launch stream)
+        # ---- roofline leg: per-launch device time of each GEMM class (hipEvents on the launch stream).
+        # The pass runs the same sketches on ONE stream so that the bracketed times are not inflated
+        # by the other chain's kernels sharing the CUs; they agree with rocprofv3's kernel durations.
+        os.environ["TTSK_SINGLE_STREAM"] = "1"
+        nat.call("ttsk_sync", -1)
         nat.call("ttsk_prof_enable", 1)
         reps = max(5, min(args.steps, 50))
         for _ in range(reps):
             plan.run(ptrs, out)
         nat.call("ttsk_sync", -1)
         classes = {}
-        # class -> (label, rocprof kernel name of the main contraction kernel at this workload)
-        names = {0: ("right chain GEMM1  T = R^T X^T", "gemm_f64_kernel<1, 4, 7, 1, false, true>"),
-                 1: ("right chain GEMM2  R' = sum T E (split-K)", "gemm_f64_kernel<1, 4, 7, 1, true, false>"),
-                 2: ("left chain GEMM1  T = L^T X", "gemm_f64_kernel<1, 4, 4, 1, false, false>"),
-                 3: ("left chain GEMM2  L' = sum T D (split-K)", "gemm_f64_kernel<4, 1, 1, 4, false, false>"),
-                 4: ("Psi GEMM  Psi = T R", "gemm_f64_kernel<4, 1, 1, 7, true, false>"),
-                 5: ("small products (Omega, first / last mode)", "gemm_f64_kernel<...> (several)")}
-        for c, (label, kname) in names.items():
+        labels = {0: "right chain GEMM1  T = R^T X^T", 1: "right chain GEMM2  R' = sum T E (split-K slabs)",
+                  2: "left chain GEMM1  T = L^T X", 3: "left chain GEMM2  L' = sum T D (split-K slabs)",
+                  4: "Psi GEMM  Psi = T R", 5: "small products (Omega, first / last mode)"}
+        for c, label in labels.items():
             n_l, ms, flops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             nat.call("ttsk_prof_read", c, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(flops))
+            kname = ctypes.create_string_buffer(96)
+            nat.call("ttsk_prof_kernel_name", c, kname, 96)
             if n_l.value:
-                classes[label] = dict(kernel=kname, launches_per_sketch=n_l.value / reps,
+                classes[label] = dict(kernel=kname.value.decode() if c != 5 else "gemm_f64_kernel<...> (several)",
+                                      launches_per_sketch=n_l.value / reps,
                                       avg_us=1e3 * ms.value / n_l.value,
                                       gflop_per_launch=flops.value / n_l.value * 1e-9,
                                       tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
                                       share_ms=ms.value / reps)
+        os.environ.pop("TTSK_SINGLE_STREAM", None)
         nat.call("ttsk_prof_enable", 0)
         dom = max(classes, key=lambda k: classes[k]["share_ms"])
         probe = ctypes.c_double()
         nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
         roofline = dict(bound="mfma", kernel=classes[dom]["kernel"], what=dom, achieved=classes[dom]["tflops"], peak=PEAK_F64_MFMA_TF,
-                        unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF, traffic=None,
+                        unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF,
+                        traffic=load_traffic(classes[dom]["kernel"]),
                         avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value,
                         classes=classes,
                         pipeline_tflops=fl["total"] * args.gpus * args.steps / elapsed * 1e-12)

@@ -124,6 +124,8 @@ int ttsk_mfma_f64_peak_probe(double *tflops);
  * 4: Psi GEMM; 5: small products (Omega, first mode); 7: untagged ttsk_gemm calls.  Only the main
  * contraction kernel of each call is bracketed (not the split-K reduce / zero fill). */
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops);
+/* rocprofv3 name of the contraction-kernel instantiation last launched for class `cls` */
+int ttsk_prof_kernel_name(int cls, char *buf, size_t len);
 
 /* ---- hash sampler (the reference's native module) -------------------------
  * Host-pointer twins of the Cython API (fast_lazy_gaussian.pyx:14,53,156,183);

@@ -60,6 +60,7 @@ def _bind(lib):
         "ttsk_prof_enable": [I],
         "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
+        "ttsk_prof_kernel_name": [I, c_char_p, S],
         "ttsk_hash_u64": [P, S],
         "ttsk_inds_to_rand_double": [P, P, I, S, I, I, c_uint64, P],
         "ttsk_inds_to_normal": [P, P, I, S, I, I, c_uint64, P],

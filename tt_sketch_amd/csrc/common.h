@@ -51,7 +51,7 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c)
 
 // per-launch device timing hooks (implemented in tt_fused.hip, used by ttsk_gemm)
 bool prof_on();
-void prof_open(hipStream_t st, double flops);
+void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, bool bk);
 void prof_close(hipStream_t st);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -230,7 +230,7 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
                  a_extent, b_extent};
     int rc;
     const bool prof = prof_on();
-    if (prof) prof_open(st, 2.0 * (double)d.batch * (double)d.M * (double)d.N * (double)K);
+    if (prof) prof_open(st, 2.0 * (double)d.batch * (double)d.M * (double)d.N * (double)K, p.family, p.tiles, ak, bk);
     if (ak && bk) rc = launch_gemm_layout<true, true>(g, st);
     else if (ak) rc = launch_gemm_layout<true, false>(g, st);
     else if (bk) rc = launch_gemm_layout<false, true>(g, st);

@@ -200,6 +200,7 @@ int ttsk_stream_wait(int waiter, int signaller)
 {
     TTSK_STREAM(sw, waiter);
     TTSK_STREAM(ss, signaller);
+    if (waiter == signaller) return TTSK_OK;
     TTSK_HIP(hipEventRecord(g_ev_sync[signaller], ss));
     TTSK_HIP(hipStreamWaitEvent(sw, g_ev_sync[signaller], 0));
     return TTSK_OK;

@@ -10,6 +10,7 @@ namespace ttsk {
 constexpr int SMAX_ROWS = 112;   // rows a fused step addresses in an X slab (tt_step.hip SMAX)
 constexpr int NCLS = 8;
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+static char g_kname[NCLS][96];
 static bool g_prof = false;
 static int g_cls = NCLS - 1;
 static std::vector<ProfRec> g_recs;
@@ -18,8 +19,13 @@ static double g_ms[NCLS], g_flops[NCLS];
 
 // called by ttsk_gemm around its main kernel launch (not the split-K reduce / zero fill)
 bool prof_on() { return g_prof; }
-void prof_open(hipStream_t st, double flops)
+void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, bool bk)
 {
+    // name of the contraction-kernel instantiation as rocprofv3 prints it
+    const int wm = family == 0 ? 2 : (family == 1 ? 1 : 4), wn = family == 0 ? 2 : (family == 1 ? 4 : 1);
+    const int tm = family == 0 ? 2 : (family == 1 ? tiles : 1), tn = family == 0 ? 2 : (family == 1 ? 1 : tiles);
+    snprintf(g_kname[g_cls], sizeof(g_kname[0]), "gemm_f64_kernel<%d, %d, %d, %d, %s, %s>", wm, wn, tm, tn,
+             ak ? "true" : "false", bk ? "true" : "false");
     ProfRec r{};
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
@@ -80,6 +86,13 @@ int ttsk_prof_enable(int on)
     return TTSK_OK;
 }
 
+int ttsk_prof_kernel_name(int cls, char *buf, size_t len)
+{
+    TTSK_ARG(cls >= 0 && cls < NCLS && buf && len > 0, "ttsk_prof_kernel_name: bad argument");
+    snprintf(buf, len, "%s", g_kname[cls]);
+    return TTSK_OK;
+}
+
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops)
 {
     TTSK_ARG(cls >= 0 && cls < NCLS, "ttsk_prof_read: class %d", cls);
@@ -123,7 +136,10 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
     // The right chain runs on the caller's stream, the left chain on a helper stream (the two are
     // independent until Psi / Omega need both); the Psi products are then dealt over both.  The
     // helper is forked from / joined into `stream`, so callers (and hipGraph capture) see one stream.
-    const int aux = (stream + 1) % TTSK_NUM_STREAMS;
+    // TTSK_SINGLE_STREAM=1 (or an active profiling pass) keeps everything on `stream`: per-kernel event
+    // times are then free of cross-stream sharing and match rocprofv3's kernel durations.
+    const char *single = getenv("TTSK_SINGLE_STREAM");
+    const int aux = (single && single[0] == '1') ? stream : (stream + 1) % TTSK_NUM_STREAMS;
     TTSK_STREAM(st_aux, aux);
     (void)st_aux;
     // workspace (per stream slot DRIVER of `stream`): Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]),
