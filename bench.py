@@ -172,15 +172,22 @@ def main():
     for _ in range(inflight):
         step_eager()
     nat.call("ttsk_sync", -1)
-    use_graph = bool(args.graph) and world == 1 and inflight == 1
+    use_graph = bool(args.graph) and world == 1
+    graphs = []
     if use_graph:
-        nat.call("ttsk_graph_begin", 0)
-        plan.run(ptrs, out)
-        nat.call("ttsk_graph_end", 0, ctypes.byref(graph))
+        # one captured graph per in-flight slot: both chains' fork / join over the slot's stream pair
+        for slot in range(inflight):
+            g = ctypes.c_void_p()
+            nat.call("ttsk_graph_begin", 2 * slot)
+            plan.run(ptrs, outs[slot], stream=2 * slot)
+            nat.call("ttsk_graph_end", 2 * slot, ctypes.byref(g))
+            graphs.append(g)
 
     def step():
         if use_graph:
-            nat.call("ttsk_graph_launch", graph, 0)
+            slot = counter[0] % inflight
+            counter[0] += 1
+            nat.call("ttsk_graph_launch", graphs[slot], 2 * slot)
         else:
             step_eager()
 

@@ -66,6 +66,46 @@ def test_contract_against_einsum(tsa):
     assert rel(got, (A * scale) @ B.T) < 1e-13
 
 
+def test_chain_kernels_against_einsum(tsa):
+    """The barrier-free chain kernels (csrc/skinny.h): streamed x small in both orientations, odd
+    extents, K tails (K % 4, K % 20), batch index joining the streamed index, strided views,
+    alpha / accumulate; long-K with one- and two-level contraction index, chunk tails, odd tile
+    counts and the operand swap.  tensor_train_drm.py:79-141 / tensor_train_sketch.py:21-35."""
+    from tt_sketch_amd.device import DevArray, contract
+    rng = np.random.default_rng(7)
+    specs = [
+        # streamed x small: small operand first / second, k-fast and m-fast streams
+        ("pq,np->qn", (100, 100), (20000, 100)), ("pq,pn->qn", (100, 50), (100, 20000)),
+        ("mk,kc->mc", (10000, 100), (100, 100)), ("pq,np->qn", (37, 53), (5001, 37)),
+        ("pq,np->qn", (1, 3), (2500, 1)), ("pq,np->qn", (50, 128), (3000, 50)),
+        ("pq,np->qn", (127, 17), (2049, 127)), ("mk,kc->mc", (2100, 13), (13, 20)),
+        ("pq,pn->qn", (22, 81), (22, 4100)), ("mk,kc->mc", (40000, 64), (64, 96)),
+        # batch joins the streamed index (right-chain GEMM1: b = k, n = p'')
+        ("pq,nkp->qkn", (100, 100), (100, 200, 100)), ("pq,nkp->qkn", (30, 21), (50, 70, 30)),
+        # long-K, both operands contiguous along their output index
+        ("qkp,qkm->pm", (100, 200, 100), (100, 200, 100)), ("kp,kq->pq", (10000, 100), (10000, 50)),
+        ("kp,kq->pq", (4100, 2), (4100, 128)), ("kp,kq->pq", (9999, 34), (9999, 66)),
+        ("qkp,qkm->pm", (7, 601, 18), (7, 601, 122)), ("qkp,qkm->pm", (300, 14, 100), (300, 14, 30)),
+        ("kp,kq->pq", (5000, 128), (5000, 128)), ("kp,kq->pq", (4097, 16), (4097, 16)),
+    ]
+    for spec, sa, sb in specs:
+        A, B = rng.standard_normal(sa), rng.standard_normal(sb)
+        got = contract(spec, DevArray.from_host(A), DevArray.from_host(B)).get()
+        assert rel(got, np.einsum(spec, A, B)) < 1e-13, spec
+    # strided small operand (rank slice), alpha and accumulate through the streamed kernel
+    R = rng.standard_normal((100, 120))
+    T = rng.standard_normal((6000, 100))
+    Rd = DevArray.from_host(R)[:, 10:110]
+    out = DevArray.from_host(np.full((6000, 100), 2.0))
+    contract("mk,kc->mc", DevArray.from_host(T), Rd, out=out, accumulate=True, alpha=-0.5)
+    assert rel(out.get(), 2.0 - 0.5 * T @ R[:, 10:110]) < 1e-13
+    # long-K with accumulate / alpha applied by the slab reduction
+    A, B = rng.standard_normal((8192, 60)), rng.standard_normal((8192, 40))
+    out = DevArray.from_host(np.ones((60, 40)))
+    contract("kp,kq->pq", DevArray.from_host(A), DevArray.from_host(B), out=out, accumulate=True, alpha=0.25)
+    assert rel(out.get(), 1 + 0.25 * A.T @ B) < 1e-13
+
+
 # ------------------------------------------------------------------ hash sampler
 def test_sampler_golden(tsa):
     from tt_sketch_amd.drm import fast_lazy_gaussian as flg

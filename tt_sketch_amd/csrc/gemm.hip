@@ -15,6 +15,7 @@
 // Split-K over (ko,ki) through gridDim.z with fp64 global atomics.
 #include <cstdlib>
 #include "gemm_kernel.h"
+#include "skinny.h"
 
 namespace ttsk {
 
@@ -176,6 +177,15 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
             TTSK_LAUNCH_CHECK();
         }
         return TTSK_OK;
+    }
+    {
+        // the chain shapes (tall-skinny, K <= 128) have their own barrier-free kernels
+        ttsk_gemm_desc n = d;
+        if (n.Ki == 1) { n.Ki = n.Ko; n.Ko = 1; n.a_ki = n.a_ko; n.b_ki = n.b_ko; }
+        else if (n.Ko > 1 && n.a_ko == n.Ki * n.a_ki && n.b_ko == n.Ki * n.b_ki) { n.Ki *= n.Ko; n.Ko = 1; }
+        const int rs = skinny_try(n, A, B, C, k_scale, stream, st);
+        if (rs < 0) return rs;
+        if (rs == 1) return TTSK_OK;
     }
     const GemmPlan p = plan_gemm(d.M, d.N);
     const int64_t tiles = d.batch * cdiv(d.M, p.bm) * cdiv(d.N, p.bn);

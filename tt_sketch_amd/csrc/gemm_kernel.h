@@ -44,8 +44,9 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_row(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // row_ror reads a valid lane everywhere, so there is no "old" value to preserve (one v_mov_dpp each)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 // value of lane (l + 4t) mod 16 of the same row of 16: row_ror:(16-4t)

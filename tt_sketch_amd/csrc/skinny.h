@@ -1,0 +1,452 @@
+// Barrier-free fp64 MFMA kernels for the two product shapes the TT chains are made of
+// (tensor_train_drm.py:79-141, tensor_train_sketch.py:21-35 in the reference):
+//
+//   "streamed x small"   C[m, j] = sum_k W[k, m] S[j, k]     j ~ 10^4..10^7 rows, K, P <= 128
+//        chain GEMM1  T = R^T X^T / T = L^T X,  Psi = T R
+//   "long-K"             C[m, n] = sum_k A[m, k] B[k, n]     M, N <= 128, K ~ 10^4..10^7
+//        chain GEMM2  R' = sum_{q,k} T E,  L' = sum_{q,k} T D
+//
+// The generic kernel (gemm_kernel.h) stages both operands through LDS behind workgroup
+// barriers; at K ~ 100 that is 3-4 barrier round trips of ~2 us each per tile and the matrix
+// pipe idles.  Here every wave runs on its own: the operand fragments of v_mfma_f64_4x4x4 are
+// exactly "lane (x = l & 15, k = l >> 4) holds element [x][k]", so a wave loads them straight
+// from HBM/L2 into the MFMA operand registers with one 8-byte buffer load per lane (rows of
+// any stride, out-of-range lanes read 0), keeps a ring of D k-blocks in flight and never
+// synchronises with its neighbours.  The small operand W is read from LDS, staged once.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace ttsk {
+
+struct SkinnyS {
+    const double *W, *S;
+    double *C;
+    int64_t w_k, w_m;   // W[k][m]
+    int64_t s_j, s_k;   // S[j][k]; with Ji < J the streamed index is two-level, j = jo Ji + ji at jo s_jo + ji s_j
+    int64_t s_jo, Ji;
+    int64_t c_m, c_j;   // C[m][j]
+    int64_t J;
+    int P, K, groups;
+    int64_t s_extent, w_extent, c_extent;   // elements addressable from each base (all < 2^29)
+    double alpha;
+    int accumulate;
+    long long *stamps;   // diagnostics (TTSK_SK_STAMPS): s_memtime at phase boundaries, 8 per workgroup
+};
+
+#define SK_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SK_STAMP_RT(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;   // beyond any num_records: loads return 0, stores are dropped
+
+// plain write-back stores: non-temporal and write-through (sc0 sc1) variants measured 10-35 % slower
+__device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, uint32_t voff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<v2i_t *>(&v), r, (int)voff, 0, 0);
+}
+
+// One workgroup = 8 free-running waves (two per SIMD, so one wave's DPP / LDS / wait slots are
+// filled by the other's MFMAs) around one LDS copy of W.  A group is 4 (+1) blocks of 16 streamed
+// rows: waves v and v+4 share row block 4g+v and split W's NPT column tiles ceil/floor; if SH,
+// the tiles of a fifth block are dealt one per wave.  For C3 (NPT = 7) that is 9,9,9,8 tile
+// strips on the four SIMDs and 1250 row blocks -> 250 workgroups = one round over 256 CUs.
+template <int NPT, int NT, bool SH, int D>
+__device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl, const int v, const int tile0,
+                                              const int tshared)
+{
+    constexpr int LDW = ldmf(16 * NPT);
+    constexpr int RB = SH ? 5 : 4;
+    constexpr int NTC = NT ? NT : 1;
+    const int lane = threadIdx.x & 63;
+    const int x16 = lane & 15, kq = lane >> 4;
+    const int KB = (a.K + 3) >> 2, ITER = (KB + D - 1) / D;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.s_extent * 8);
+    const uint32_t kstep = (uint32_t)(4 * a.s_k * 8);
+    const int nkb_lane = (a.K - kq + 3) >> 2;          // k-blocks in which this lane's k = 4 kb + kq is < K
+    const bool sh_on = SH && tshared < NPT;
+
+    auto lane_off = [&](int64_t rb) -> uint32_t {
+        const int64_t j = rb * 16 + x16;
+        if (a.Ji >= a.J) return (uint32_t)((j * a.s_j + (int64_t)kq * a.s_k) * 8);
+        const uint32_t jo = (uint32_t)j / (uint32_t)a.Ji, ji = (uint32_t)j - jo * (uint32_t)a.Ji;
+        return (uint32_t)(((int64_t)jo * a.s_jo + (int64_t)ji * a.s_j + (int64_t)kq * a.s_k) * 8);
+    };
+    // masked lanes (k >= K, group past the end) read offset OOB_OFF = 0.0
+    auto fetch = [&](uint32_t base, int nkb, int kb) -> double {
+        return ld8(rs, kb < nkb ? base : OOB_OFF, (uint32_t)kb * kstep);
+    };
+
+    int g = blockIdx.x;
+    int nkb = g < a.groups ? nkb_lane : 0;
+    uint32_t voA = lane_off((int64_t)g * RB + v), voB = lane_off((int64_t)g * RB + 4);
+    double ringA[D], ringB[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (NT) ringA[d] = fetch(voA, nkb, d);
+        if (SH) ringB[d] = fetch(voB, sh_on ? nkb : 0, d);
+    }
+
+    SK_STAMP(1);
+    __syncthreads();   // W staged by the caller's loads; every wave reaches this exactly once
+    SK_STAMP(2);
+
+    const double *wl_lane = Wl + kq * LDW + x16 + 16 * tile0;
+    const int soffS = 16 * (sh_on ? tshared : 0) - 16 * tile0;
+
+    double accA[NTC][4], accB[4];
+#pragma unroll
+    for (int p = 0; p < NTC; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accA[p][t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accB[t] = 0.0;
+
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.C, a.c_extent * 8);
+    // acc[t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is D[4 beta + i][4((beta+t)&3) + j4]
+    const int e_m = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    int e_j[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) e_j[t] = 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+    const uint32_t tile_step = (uint32_t)(16 * a.c_m * 8);
+
+    while (g < a.groups) {
+        uint32_t nA = voA, nB = voB;
+        int nkb_n = nkb;
+        auto kblock = [&](int it, int itn, int d) {
+            const int kb = it * D + d;
+            const double *wk = wl_lane + kb * 4 * LDW;
+            double af[NTC], as = 0.0;
+#pragma unroll
+            for (int p = 0; p < NT; ++p) af[p] = wk[16 * p];
+            if (SH) as = wk[soffS];
+            double rA[4], rB[4];
+            if (NT) {
+                rot4(ringA[d], rA);
+                ringA[d] = fetch(nA, nkb_n, itn * D + d);
+            }
+            if (SH) {
+                rot4(ringB[d], rB);
+                ringB[d] = fetch(nB, sh_on ? nkb_n : 0, itn * D + d);
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accA[p][t] = mfma4(af[p], rA[t], accA[p][t]);
+            if (SH) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accB[t] = mfma4(as, rB[t], accB[t]);
+            }
+        };
+        for (int it = 0; it < ITER - 1; ++it) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) kblock(it, it + 1, d);
+        }
+        {
+            // last iteration of the group: its loads are the next group's first k-blocks; k-blocks
+            // past K (ring slots padded to a multiple of D) are loaded as zeros and not multiplied
+            const int gn = g + gridDim.x;
+            nA = lane_off((int64_t)gn * RB + v);
+            nB = lane_off((int64_t)gn * RB + 4);
+            nkb_n = gn < a.groups ? nkb_lane : 0;
+            const int last = KB - (ITER - 1) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (d < last) {
+                    kblock(ITER - 1, 0, d);
+                } else {
+                    if (NT) ringA[d] = fetch(nA, nkb_n, d);
+                    if (SH) ringB[d] = fetch(nB, sh_on ? nkb_n : 0, d);
+                }
+            }
+        }
+        SK_STAMP(3);
+        // epilogue: branch-free buffer stores, masked lanes go out of range
+        {
+            const int64_t jA = ((int64_t)g * RB + v) * 16, jB = ((int64_t)g * RB + 4) * 16;
+            uint32_t offs[NTC][4], offt[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t ja = jA + e_j[t], jb = jB + e_j[t];
+                const uint32_t oa = (uint32_t)((ja * a.c_j + (int64_t)e_m * a.c_m) * 8);
+                const uint32_t ob = (uint32_t)((jb * a.c_j + (int64_t)e_m * a.c_m) * 8);
+#pragma unroll
+                for (int p = 0; p < NT; ++p) {
+                    offs[p][t] = (ja < a.J && 16 * (tile0 + p) + e_m < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
+                    accA[p][t] *= a.alpha;
+                }
+                offt[t] = (sh_on && jb < a.J && 16 * tshared + e_m < a.P) ? ob + tshared * tile_step : OOB_OFF;
+                accB[t] *= a.alpha;
+            }
+            if (a.accumulate) {
+                double old[NTC][4], olds[4];
+#pragma unroll
+                for (int p = 0; p < NT; ++p)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) old[p][t] = ld8(rc, offs[p][t], 0);
+                if (SH) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) olds[t] = ld8(rc, offt[t], 0);
+                }
+#pragma unroll
+                for (int p = 0; p < NT; ++p)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accA[p][t] += old[p][t];
+                if (SH) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accB[t] += olds[t];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    st8(rc, offs[p][t], accA[p][t]);
+                    accA[p][t] = 0.0;
+                }
+            if (SH) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    st8(rc, offt[t], accB[t]);
+                    accB[t] = 0.0;
+                }
+            }
+        }
+        SK_STAMP(4);
+        g += gridDim.x;
+        voA = nA;
+        voB = nB;
+        nkb = nkb_n;
+    }
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        SK_STAMP(5);
+        SK_STAMP_RT(7);
+    }
+}
+
+template <int NPT, bool SH, int D>
+__global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
+{
+    extern __shared__ double Wl[];
+    constexpr int LDW = ldmf(16 * NPT);
+    const int tid = threadIdx.x;
+    SK_STAMP(0);
+    SK_STAMP_RT(6);
+    // stage W once: Wl[k][m], zero beyond (K, P).  All loads of a thread are issued before the first
+    // LDS store (one memory round trip); masked elements read out of range = 0.  The streamed
+    // operand's first ring loads are issued by skinny_s_wave before it joins the barrier.
+    {
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.W, a.w_extent * 8);
+        const int krows = ((a.K + 3) >> 2) * 4;
+        constexpr int HW = 8 * NPT;                       // pairs per LDS row
+        const int total = krows * HW;
+        const bool vec = a.w_m == 1 && !(a.w_k & 1) && !(a.P & 1) && !((uintptr_t)a.W & 15);
+        constexpr int BATCH = 12;
+        for (int e0 = tid; e0 < total; e0 += 512 * BATCH) {
+            double2 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int k = e / HW, m = 2 * (e - k * HW);
+                const bool ok = e < total && k < a.K;
+                const uint32_t o0 = (ok && m < a.P) ? (uint32_t)((k * a.w_k + m * a.w_m) * 8) : OOB_OFF;
+                if (vec) {
+                    v[u] = ld16(rw, o0, 0);
+                } else {
+                    const uint32_t o1 = (ok && m + 1 < a.P) ? (uint32_t)((k * a.w_k + (m + 1) * a.w_m) * 8) : OOB_OFF;
+                    v[u].x = ld8(rw, o0, 0);
+                    v[u].y = ld8(rw, o1, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int k = e / HW, m = 2 * (e - k * HW);
+                if (e < total) *reinterpret_cast<double2 *>(&Wl[k * LDW + m]) = v[u];
+            }
+        }
+    }
+    const int w = tid >> 6, v = w & 3;
+    constexpr int H0 = (NPT + 1) / 2, H1 = NPT / 2;
+    if (w < 4) skinny_s_wave<NPT, H0, SH, D>(a, Wl, v, 0, w);
+    else       skinny_s_wave<NPT, H1, SH, D>(a, Wl, v, H0, w);
+}
+
+// ---- long-K products -------------------------------------------------------------------
+// C[m, n] = sum_kappa A[kappa][m] B[kappa][n] with m and n contiguous in memory (both chain
+// GEMM2s after the driver lays T out that way), kappa = (ko, ki) with per-operand strides.
+// One workgroup = one chunk of kappa against the whole (<= 128 x 128) output; its 8 waves tile
+// the output as 2 row halves x 4 column strips and stream exactly the A rows and B columns of
+// their tiles straight into MFMA operand registers (ring of D kappa-blocks in flight, no LDS, no
+// barriers).  The vector memory pipe is the scarce unit here (every MFMA operand comes from
+// memory), so tiles are fetched in pairs: one 16-byte load per lane brings rows 2x and 2x+1 of a
+// 32-row block, i.e. the fragments of the "even rows" and the "odd rows" tile at once, 256
+// contiguous bytes per kappa.  Partial outputs go to slab[chunk][m][n]; skinny_r_reduce sums them.
+struct SkinnyR {
+    const double *A, *B;
+    double *slab;
+    int64_t a_ko, a_ki, b_ko, b_ki;
+    int64_t Ki, K, chunk;
+    int64_t a_extent, b_extent;
+    int M, N;
+    long long *stamps;
+};
+
+__device__ __forceinline__ void st16(double *p, double x, double y)
+{
+    *reinterpret_cast<double2 *>(p) = make_double2(x, y);
+}
+
+// Wave tile: rows [row0, row0 + 32 PA + 16 SA) x columns [col0, col0 + 32 PB + 16 SB):
+// PA / PB paired 32-blocks and an optional single 16-block per side.
+template <int PA, int SA, int PB, int SB, int D>
+__device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, const int col0)
+{
+    constexpr int TM = 2 * PA + SA, TN = 2 * PB + SB;
+    const int lane = threadIdx.x & 63;
+    const int x16 = lane & 15, kq = lane >> 4;
+    SK_STAMP(0);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.A, a.a_extent * 8);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.B, a.b_extent * 8);
+    const int64_t k0 = (int64_t)blockIdx.x * a.chunk;
+    const int64_t len = a.K - k0 < a.chunk ? a.K - k0 : a.chunk;
+    const int nkb_lane = (int)((len - kq + 3) >> 2);
+    const int KB = (int)((len + 3) >> 2);
+
+    // per-lane walk over kappa = k0 + kq + 4 i: byte offsets of A's and B's kappa part
+    const int64_t kap = k0 + kq;
+    const int64_t ko0 = a.Ki == a.K ? 0 : kap / a.Ki;
+    int ki = (int)(kap - ko0 * a.Ki);
+    uint32_t offA = (uint32_t)((ko0 * a.a_ko + (int64_t)ki * a.a_ki) * 8);
+    uint32_t offB = (uint32_t)((ko0 * a.b_ko + (int64_t)ki * a.b_ki) * 8);
+    const uint32_t stepA = (uint32_t)(4 * a.a_ki * 8), stepB = (uint32_t)(4 * a.b_ki * 8);
+    const uint32_t wrapA = (uint32_t)((a.a_ko - a.Ki * a.a_ki) * 8), wrapB = (uint32_t)((a.b_ko - a.Ki * a.b_ki) * 8);
+    const int Ki = (int)a.Ki;
+    // column (element) offsets inside a kappa row; elements past M / N are masked per lane
+    uint32_t rowA[PA + SA], colB[PB + SB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) rowA[p] = row0 + 32 * p + 2 * x16 < a.M ? (uint32_t)(row0 + 32 * p + 2 * x16) * 8u : OOB_OFF;
+    if (SA) rowA[PA] = row0 + 32 * PA + x16 < a.M ? (uint32_t)(row0 + 32 * PA + x16) * 8u : OOB_OFF;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) colB[q] = col0 + 32 * q + 2 * x16 < a.N ? (uint32_t)(col0 + 32 * q + 2 * x16) * 8u : OOB_OFF;
+    if (SB) colB[PB] = col0 + 32 * PB + x16 < a.N ? (uint32_t)(col0 + 32 * PB + x16) * 8u : OOB_OFF;
+
+    double ringA[D][TM], ringB[D][TN];
+    int kb_load = 0;
+    auto issue = [&](int d) {
+        const bool ok = kb_load < nkb_lane;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const double2 v = ld16(ra, (ok && rowA[p] != OOB_OFF) ? rowA[p] + offA : OOB_OFF, 0);
+            ringA[d][2 * p] = v.x;
+            ringA[d][2 * p + 1] = v.y;
+        }
+        if (SA) ringA[d][2 * PA] = ld8(ra, (ok && rowA[PA] != OOB_OFF) ? rowA[PA] + offA : OOB_OFF, 0);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const double2 v = ld16(rb, (ok && colB[q] != OOB_OFF) ? colB[q] + offB : OOB_OFF, 0);
+            ringB[d][2 * q] = v.x;
+            ringB[d][2 * q + 1] = v.y;
+        }
+        if (SB) ringB[d][2 * PB] = ld8(rb, (ok && colB[PB] != OOB_OFF) ? colB[PB] + offB : OOB_OFF, 0);
+        ++kb_load;
+        ki += 4;
+        offA += stepA;
+        offB += stepB;
+        const bool wrap = ki >= Ki;
+        ki = wrap ? ki - Ki : ki;
+        offA += wrap ? wrapA : 0u;
+        offB += wrap ? wrapB : 0u;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d);
+
+    double acc[TM][TN][4];
+#pragma unroll
+    for (int p = 0; p < TM; ++p)
+#pragma unroll
+        for (int q = 0; q < TN; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[p][q][t] = 0.0;
+
+    SK_STAMP(1);
+    auto kblock = [&](int d, bool more) {
+        double af[TM], rB[TN][4];
+#pragma unroll
+        for (int p = 0; p < TM; ++p) af[p] = ringA[d][p];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) rot4(ringB[d][q], rB[q]);
+        if (more) issue(d);
+#pragma unroll
+        for (int p = 0; p < TM; ++p)
+#pragma unroll
+            for (int q = 0; q < TN; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[p][q][t] = mfma4(af[p], rB[q][t], acc[p][q][t]);
+    };
+    const int FULLIT = KB / D, TAIL = KB - FULLIT * D;
+    for (int it = 0; it < FULLIT; ++it) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) kblock(d, true);
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < TAIL) kblock(d, false);
+    SK_STAMP(3);
+    // acc[p][q][t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is fragment element
+    // (r = 4 beta + i, c = 4((beta+t)&3) + j4); pair fragments 2p / 2p+1 are rows 32p + 2r + {0,1}
+    double *slab = a.slab + (int64_t)blockIdx.x * a.M * a.N;
+    const int r16 = 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+    for (int p = 0; p < TM; ++p) {
+        const int m = p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16;
+        if (m < a.M) {
+            double *srow = slab + (int64_t)m * a.N;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c16 = 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+#pragma unroll
+                for (int q = 0; q < PB; ++q) {
+                    const int n = col0 + 32 * q + 2 * c16;     // even N (16-byte loads) => n + 1 < N too
+                    if (n < a.N) st16(srow + n, acc[p][2 * q][t], acc[p][2 * q + 1][t]);
+                }
+                if (SB) {
+                    const int n = col0 + 32 * PB + c16;
+                    if (n < a.N) srow[n] = acc[p][2 * PB][t];
+                }
+            }
+        }
+    }
+    SK_STAMP(4);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        SK_STAMP(5);
+    }
+}
+
+template <int NMT, int NNT, int D>
+__global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
+{
+    constexpr int H0 = (NMT + 1) / 2, H1 = NMT / 2;          // tiles of the two row halves
+    constexpr int TN = (NNT + 3) / 4;                        // tiles per column strip (1 or 2)
+    constexpr int FULL = NNT / TN, REST = NNT - FULL * TN;   // FULL strips of TN tiles, then one of REST
+    const int w = threadIdx.x >> 6, s = w & 3, h = w >> 2;
+    if (h == 0) {
+        if (s < FULL) skinny_r_wave<H0 / 2, H0 % 2, TN / 2, TN % 2, D>(a, 0, 16 * s * TN);
+        if constexpr (REST > 0) {
+            if (s == FULL) skinny_r_wave<H0 / 2, H0 % 2, REST / 2, REST % 2, D>(a, 0, 16 * s * TN);
+        }
+    } else {
+        if constexpr (H1 > 0) {
+            if (s < FULL) skinny_r_wave<H1 / 2, H1 % 2, TN / 2, TN % 2, D>(a, 16 * H0, 16 * s * TN);
+            if constexpr (REST > 0) {
+                if (s == FULL) skinny_r_wave<H1 / 2, H1 % 2, REST / 2, REST % 2, D>(a, 16 * H0, 16 * s * TN);
+            }
+        }
+    }
+}
+
+// 1 = launched, 0 = shape not covered (caller falls through to the generic kernel), < 0 = error
+int skinny_try(const ttsk_gemm_desc &d, const double *A, const double *B, double *C, const double *k_scale,
+               int stream, hipStream_t st);
+
+}  // namespace ttsk

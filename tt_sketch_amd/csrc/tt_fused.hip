@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <vector>
 #include "common.h"
+#include "skinny.h"
 #include "tt_step.h"
 
 namespace ttsk {
@@ -11,6 +12,7 @@ constexpr int SMAX_ROWS = 112;   // rows a fused step addresses in an X slab (tt
 constexpr int NCLS = 8;
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 static char g_kname[NCLS][96];
+static double g_kname_flops[NCLS];   // the name kept per class is that of its largest launch
 static bool g_prof = false;
 static int g_cls = NCLS - 1;
 static std::vector<ProfRec> g_recs;
@@ -24,8 +26,16 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     // name of the contraction-kernel instantiation as rocprofv3 prints it
     const int wm = family == 0 ? 2 : (family == 1 ? 1 : 4), wn = family == 0 ? 2 : (family == 1 ? 4 : 1);
     const int tm = family == 0 ? 2 : (family == 1 ? tiles : 1), tn = family == 0 ? 2 : (family == 1 ? 1 : tiles);
-    snprintf(g_kname[g_cls], sizeof(g_kname[0]), "gemm_f64_kernel<%d, %d, %d, %d, %s, %s>", wm, wn, tm, tn,
-             ak ? "true" : "false", bk ? "true" : "false");
+    if (flops < g_kname_flops[g_cls]) family = -1;
+    else g_kname_flops[g_cls] = flops;
+    if (family < 0) {
+    } else if (family == 3)        // streamed x small: tiles = column tiles of the small operand, ak = shared fifth block
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %s, 5>", tiles, ak ? "true" : "false");
+    else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_r_kernel<%d, %d, 4>", tiles / 10, tiles % 10);
+    else
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "gemm_f64_kernel<%d, %d, %d, %d, %s, %s>", wm, wn, tm, tn,
+                 ak ? "true" : "false", bk ? "true" : "false");
     ProfRec r{};
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
@@ -68,6 +78,24 @@ static int gemm(int cls, int64_t M, int64_t N, int64_t Ko, int64_t Ki, const dou
     return rc;
 }
 
+// Right-chain GEMM1 in the layout the long-K kernel wants, T[q][k][p''] (p'' contiguous):
+// a product batched over k whose batch index joins the streamed index.  1 = launched by the
+// streamed-x-small kernel, 0 = shape not covered (caller uses the generic layout), < 0 = error.
+static int right_gemm1_batched(int cls, int64_t rho, int64_t sn, int64_t nn, int64_t sp, const double *Rc,
+                               const double *X, double *T, int stream, hipStream_t st)
+{
+    ttsk_gemm_desc d{};
+    d.batch = nn; d.M = rho; d.N = sn; d.Ko = 1; d.Ki = sp;
+    d.a_b = 0; d.a_m = 1; d.a_ko = 0; d.a_ki = rho;
+    d.b_b = sp; d.b_ko = 0; d.b_ki = 1; d.b_n = nn * sp;
+    d.c_b = sn; d.c_m = nn * sn; d.c_n = 1;
+    d.alpha = 1.0; d.accumulate = 0; d.split_k = 0;
+    g_cls = cls;
+    const int rc = skinny_try(d, Rc, X, T, nullptr, stream, st);
+    g_cls = NCLS - 1;
+    return rc;
+}
+
 }  // namespace ttsk
 
 using namespace ttsk;
@@ -80,7 +108,7 @@ int ttsk_prof_enable(int on)
     if (!on) prof_flush();
     else {
         prof_flush();
-        for (int i = 0; i < NCLS; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_flops[i] = 0; }
+        for (int i = 0; i < NCLS; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_flops[i] = 0; g_kname_flops[i] = 0; }
     }
     g_prof = on != 0;
     return TTSK_OK;
@@ -266,10 +294,19 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
                 CK(gemm(5, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
             } else {
                 const double *Rc = ws + offR[j - 1];                   // (sp x rho)
-                // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
-                CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
-                // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
-                CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+                // preferred: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (batched over k), so that both
+                // operands of GEMM2 are contiguous along their output index
+                const int fast = right_gemm1_batched(0, rho, sn, nn, sp, Rc, X[mu], T, stream, st);
+                if (fast < 0) return fast;
+                if (fast == 1) {
+                    // Rn[p'', q'] = sum_{q,k} T[q,k,p''] E[q,k,q']
+                    CK(gemm(1, sn, rhop, rho, nn, T, 1, nn * sn, sn, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+                } else {
+                    // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
+                    CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
+                    // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
+                    CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
+                }
             }
         }
     }
@@ -285,7 +322,7 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
         double *T = ws + offT[mu];
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
-        CK(gemm(2, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
+        CK(gemm(mu == d - 1 ? 5 : 2, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
         if (mu < d - 1)
             // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
             CK(gemm(3, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1, ws + offL[mu],
