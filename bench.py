@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--batch", type=int, default=1, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent sketches in flight (items of the tensor stream are issued on alternating "
@@ -149,26 +150,37 @@ def main():
         uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.numpy().tobytes()))
         nat.call("ttsk_comm_init", uid, rank, world)
 
+    B = max(1, int(args.batch))
     shape, cores, lcores, rcores = make_inputs(seed=3 + rank)
     _, _, lcores, rcores = (shape, cores) + tuple(make_inputs(seed=3)[2:])   # DRMs shared by all ranks
-    tt = TensorTrain(cores)
+    all_cores = [cores] + [make_inputs(seed=3 + rank + 1000 * b)[1] for b in range(1, B)]   # B different TTs
+    tts = [TensorTrain(c) for c in all_cores]
+    tt = tts[0]
     left = TensorTrainDRM(L_RANK, shape, False, seed=1, cores=lcores)
     right = TensorTrainDRM(R_RANK, shape, True, seed=2, cores=rcores)
     plan = TTSketchPlan(tt.shape, tt.rank, left, right)
     inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
-    outs = [plan.new_buffer() for _ in range(inflight)]
+    from tt_sketch_amd.device import DevArray
+    outs = [DevArray.empty((B * plan.size,)) for _ in range(inflight)]
     out = outs[0]
-    ptrs, keep = plan.core_pointers(tt)
+    keep, flat = [], []
+    for t in tts:
+        p1, k1 = plan.core_pointers(t)
+        keep.append(k1)
+        flat += [p1[i] for i in range(plan.d)]
+    ptrs = (ctypes.c_void_p * len(flat))(*flat)
     counter = [0]
+
+    def run_on(slot):
+        plan.run_batch(ptrs, B, outs[slot], plan.size, stream=2 * slot)   # stream pair (2 slot, 2 slot + 1)
 
     def step_eager():
         slot = counter[0] % inflight
         counter[0] += 1
-        plan.run(ptrs, outs[slot], stream=2 * slot)          # stream pair (2 slot, 2 slot + 1)
+        run_on(slot)
         if world > 1:
-            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(outs[slot].ptr), ctypes.c_size_t(plan.size), 2 * slot)
+            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(outs[slot].ptr), ctypes.c_size_t(B * plan.size), 2 * slot)
 
-    graph = ctypes.c_void_p()
     for _ in range(inflight):
         step_eager()
     nat.call("ttsk_sync", -1)
@@ -179,7 +191,7 @@ def main():
         for slot in range(inflight):
             g = ctypes.c_void_p()
             nat.call("ttsk_graph_begin", 2 * slot)
-            plan.run(ptrs, outs[slot], stream=2 * slot)
+            run_on(slot)
             nat.call("ttsk_graph_end", 2 * slot, ctypes.byref(g))
             graphs.append(g)
 
@@ -221,7 +233,7 @@ def main():
         nat.call("ttsk_prof_enable", 1)
         reps = max(5, min(args.steps, 50))
         for _ in range(reps):
-            plan.run(ptrs, out)
+            run_on(0)
         nat.call("ttsk_sync", -1)
         classes = {}
         labels = {0: "right chain GEMM1  T = R^T X^T", 1: "right chain GEMM2  R' = sum T E (split-K slabs)",
@@ -234,7 +246,7 @@ def main():
             nat.call("ttsk_prof_kernel_name", c, kname, 96)
             if n_l.value:
                 classes[label] = dict(kernel=kname.value.decode() if c != 5 else "gemm_f64_kernel<...> (several)",
-                                      launches_per_sketch=n_l.value / reps,
+                                      launches_per_step=n_l.value / reps,
                                       avg_us=1e3 * ms.value / n_l.value,
                                       gflop_per_launch=flops.value / n_l.value * 1e-9,
                                       tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
@@ -249,27 +261,34 @@ def main():
                         traffic=load_traffic(classes[dom]["kernel"]),
                         avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value,
                         classes=classes,
-                        pipeline_tflops=fl["total"] * args.gpus * args.steps / elapsed * 1e-12)
+                        pipeline_tflops=fl["total"] * B * args.gpus * args.steps / elapsed * 1e-12)
         cpu = None
         parity = None
         if not args.no_cpu:
             cpu, ref = cpu_baseline(shape, cores, lcores, rcores)
             if world == 1:
-                got = out.get()
+                got = out.get()[:plan.size]
                 want = np.concatenate([a.ravel() for a in ref[0] + ref[1]])
                 parity = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+                if B > 1:   # the last tensor of the batch against the oracle as well
+                    import oracle.ttsk_oracle as orc
+                    ld, rd = orc.TTDrm(lcores, shape, False), orc.TTDrm(rcores, shape, True)
+                    rP, rO = orc.general_sketch("tt", all_cores[-1], ld, rd, "streaming")
+                    want = np.concatenate([a.ravel() for a in rP + rO])
+                    got = out.get()[(B - 1) * plan.size:B * plan.size]
+                    parity = max(parity, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
         ms_step = 1e3 * elapsed / args.steps
         result = dict(metric="TT-cores sketched/sec (fp64), stream_sketch d=6 n=200 r=50",
-                      value=D * args.gpus * args.steps / elapsed, unit="TT-cores/s", n_gpus=args.gpus,
+                      value=D * B * args.gpus * args.steps / elapsed, unit="TT-cores/s", n_gpus=args.gpus,
                       steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
                       scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                       config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / "
                                            "right rank 100, streaming sketch (both chains, Omega, Psi), "
-                                           f"one TT per GPU per step, {inflight} independent sketches in flight" +
+                                           f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight" +
                                            ("; partial sketches summed by one RCCL all-reduce" if world > 1 else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
-                                  sketches_in_flight=inflight,
+                                  tts_per_step=B, steps_in_flight=inflight,
                                   sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
         print(json.dumps(result))

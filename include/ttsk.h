@@ -110,6 +110,16 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
                    const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                    const double *const *X, const double *const *DL, const double *const *DR,
                    double *out, int accumulate, int stream);
+/* The same for nb tensors of ONE signature (n, s) against the same DRMs: X[b*d + mu] is core mu of
+ * tensor b, sketch b goes to out + b*out_stride (out_stride >= ttsk_tt_sketch_size, ignored for
+ * nb == 1).  Every chain product is then a single launch over all nb tensors -- the kernels'
+ * fixed costs (launch gap, staging the small operand, pipeline fill and drain) are paid once per
+ * batch.  This is the term loop of a TensorSum input (sketch_dispatch.py:85-139) and the
+ * throughput mode bench.py measures. */
+int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                         const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                         const double *const *X, const double *const *DL, const double *const *DR,
+                         double *out, int64_t out_stride, int accumulate, int stream);
 /* number of doubles ttsk_tt_sketch writes to `out` */
 int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
                             const int64_t *r_lo, const int64_t *r_hi);

@@ -384,22 +384,36 @@ def test_one_call_tt_path_matches_generic_and_oracle(tsa):
             assert rel(a.get(), c) < TOL and rel(b.get(), c) < TOL
 
 
-def test_fused_step_kernel_opt_in(tsa, monkeypatch):
-    """The per-mode fused chain-step kernel (csrc/tt_step.hip, opt-in) gives the same sketch."""
+def test_batched_one_call_path(tsa):
+    """ttsk_tt_sketch_batch: nb tensors of one signature in one pass give, tensor by tensor, the
+    sketch of the single-tensor call and of the oracle (rank slices included; nb > 8 is sliced)."""
+    import ctypes
     from tt_sketch_amd import tt_fused
     from tests.gpu_build import make_drm, make_tensor
-    rng = np.random.default_rng(12)
-    for shape, s, lr, rr in (((9, 12, 7, 10, 8), (3, 6, 5, 4), (4, 7, 6, 5), (6, 9, 8, 7)),
-                             ((20, 33, 18, 25), (40, 70, 35), (30, 50, 20), (45, 100, 60))):
-        cores = orc.random_tt(shape, s, rng)
+    rng = np.random.default_rng(23)
+    for shape, ranks, lr, rr, nb in [((9, 12, 7, 10, 8), (3, 6, 5, 4), (4, 7, 6, 5), (6, 9, 8, 7), 3),
+                                     ((64, 48, 64), (40, 36), (20, 24), (30, 28), 2),
+                                     ((5, 4, 6), (3, 2), (2, 3), (4, 3), 11)]:
         ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
         if len(shape) == 5:
             ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)
-            rd.rank_min, rd.rank_max = (0, 3, 1, 2), (5, 8, 9, 6)
-        oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
-        monkeypatch.setenv("TTSK_FUSED_STEP", "1")
-        fused = tt_fused.try_stream_sketch(make_tensor("tt", cores), make_drm(ld), make_drm(rd),
-                                           tsa.SketchMethod.streaming)
-        monkeypatch.delenv("TTSK_FUSED_STEP")
-        for a, c in zip(fused[0] + fused[1], oP + oO):
-            assert rel(a.get(), c) < TOL
+            rd.rank_min, rd.rank_max = (0, 3, 1, 2), (5, 8, 9, 6)       # walking order of the right DRM
+        L, R = make_drm(ld), make_drm(rd)
+        tts = [orc.random_tt(shape, ranks, rng) for _ in range(nb)]
+        dev = [make_tensor("tt", c) for c in tts]
+        plan = tt_fused.TTSketchPlan(dev[0].shape, dev[0].rank, L, R)
+        keep, flat = [], []
+        for t in dev:
+            ptrs, k = plan.core_pointers(t)
+            keep.append(k)
+            flat += [ptrs[i] for i in range(plan.d)]
+        X = (ctypes.c_void_p * len(flat))(*flat)
+        stride = plan.size + 5
+        from tt_sketch_amd.device import DevArray
+        out = DevArray.zeros((nb * stride,))
+        plan.run_batch(X, nb, out, stride)
+        for b, cores in enumerate(tts):
+            oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
+            Psi, Om = plan.views(out[b * stride:b * stride + plan.size])
+            for a, c in zip(Psi + Om, oP + oO):
+                assert rel(a.get(), c) < TOL

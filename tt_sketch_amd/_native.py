@@ -57,6 +57,7 @@ def _bind(lib):
         "ttsk_copy_strided": [P, P, I, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), I],
         "ttsk_axpby": [P, P, c_double, c_double, S, I],
         "ttsk_tt_sketch": [I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
+        "ttsk_tt_sketch_batch": [I, I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, c_int64, I, I],
         "ttsk_prof_enable": [I],
         "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],

@@ -18,12 +18,19 @@
 
 namespace ttsk {
 
+constexpr int SK_MAXB = 8;   // problems of one shape per launch (one tensor of a batch each)
+
 struct SkinnyS {
-    const double *W, *S;
-    double *C;
+    const double *W[SK_MAXB], *S[SK_MAXB];
+    double *C[SK_MAXB];
+    int nb, wpp;        // problems, workgroups per problem: workgroup x serves problem x / wpp
     int64_t w_k, w_m;   // W[k][m]
-    int64_t s_j, s_k;   // S[j][k]; with Ji < J the streamed index is two-level, j = jo Ji + ji at jo s_jo + ji s_j
-    int64_t s_jo, Ji;
+    int64_t s_j, s_k;   // S[j][k]
+    // Two-level streamed index j = u V + v (u < U at stride s_u, v < V at stride s_j; U = 1: plain).
+    // A 16-row block is then a (16 >> tvl) (u) x (1 << tvl) (v) tile, tvl = 2, 3 or 4: the right
+    // chain's GEMM1 reads X[p'', k, :] for a few consecutive k of a few p'' and writes T[q][k][p''].
+    int64_t s_u;
+    int U, V, nbv, tvl;
     int64_t c_m, c_j;   // C[m][j]
     int64_t J;
     int P, K, groups;
@@ -36,12 +43,61 @@ struct SkinnyS {
 #define SK_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define SK_STAMP_RT(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
+// A pointer picked from a kernel-argument array by a workgroup-uniform index: tell the compiler it
+// is wave-uniform, or every buffer load through its resource descriptor gets a waterfall loop.
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
+
 constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;   // beyond any num_records: loads return 0, stores are dropped
 
 // plain write-back stores: non-temporal and write-through (sc0 sc1) variants measured 10-35 % slower
 __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, uint32_t voff, double v)
 {
     __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<v2i_t *>(&v), r, (int)voff, 0, 0);
+}
+
+// Stage W once per workgroup: Wl[k][m], zero beyond (K, P).  All loads of a thread are issued
+// before the first LDS store (one memory round trip); masked elements read out of range = 0.
+template <int NPT, int D>
+__device__ __forceinline__ void skinny_s_stage(const SkinnyS &a, double *Wl)
+{
+    constexpr int LDW = ldmf(16 * NPT);
+    const int tid = threadIdx.x;
+    const double *Wp = uniform_ptr(a.W[blockIdx.x / a.wpp]);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, a.w_extent * 8);
+    const int KB = (a.K + 3) >> 2, krows = ((KB + D - 1) / D) * D * 4;
+    constexpr int HW = 8 * NPT;                       // pairs per LDS row
+    const int total = krows * HW;
+    const bool vec = a.w_m == 1 && !(a.w_k & 1) && !(a.P & 1) && !((uintptr_t)Wp & 15);
+    constexpr int BATCH = 12;
+    for (int e0 = tid; e0 < total; e0 += 512 * BATCH) {
+        double2 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = e0 + 512 * u;
+            const int k = e / HW, m = 2 * (e - k * HW);
+            const bool ok = e < total && k < a.K;
+            const uint32_t o0 = (ok && m < a.P) ? (uint32_t)((k * a.w_k + m * a.w_m) * 8) : OOB_OFF;
+            if (vec) {
+                v[u] = ld16(rw, o0, 0);
+            } else {
+                const uint32_t o1 = (ok && m + 1 < a.P) ? (uint32_t)((k * a.w_k + (m + 1) * a.w_m) * 8) : OOB_OFF;
+                v[u].x = ld8(rw, o0, 0);
+                v[u].y = ld8(rw, o1, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = e0 + 512 * u;
+            const int k = e / HW, m = 2 * (e - k * HW);
+            if (e < total) *reinterpret_cast<double2 *>(&Wl[k * LDW + m]) = v[u];
+        }
+    }
 }
 
 // One workgroup = 8 free-running waves (two per SIMD, so one wave's DPP / LDS / wait slots are
@@ -59,23 +115,35 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     const int lane = threadIdx.x & 63;
     const int x16 = lane & 15, kq = lane >> 4;
     const int KB = (a.K + 3) >> 2, ITER = (KB + D - 1) / D;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.s_extent * 8);
+    const int prob = blockIdx.x / a.wpp, wg = blockIdx.x - prob * a.wpp;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(uniform_ptr(a.S[prob]), a.s_extent * 8);
     const uint32_t kstep = (uint32_t)(4 * a.s_k * 8);
     const int nkb_lane = (a.K - kq + 3) >> 2;          // k-blocks in which this lane's k = 4 kb + kq is < K
     const bool sh_on = SH && tshared < NPT;
 
+    // streamed row c16 of row block rb: its index j (also the output column), or -1 past the end
+    auto row_of = [&](int64_t rb, int c16, int64_t &in_off) -> int64_t {
+        if (a.U == 1) {
+            const int64_t j = rb * 16 + c16;
+            in_off = j * a.s_j;
+            return j < a.J ? j : -1;
+        }
+        const int bu = (int)((uint32_t)rb / (uint32_t)a.nbv), bv = (int)rb - bu * a.nbv;
+        const int u = (bu << (4 - a.tvl)) + (c16 >> a.tvl), vv = (bv << a.tvl) + (c16 & ((1 << a.tvl) - 1));
+        in_off = (int64_t)u * a.s_u + (int64_t)vv * a.s_j;
+        return (u < a.U && vv < a.V) ? (int64_t)u * a.V + vv : -1;
+    };
     auto lane_off = [&](int64_t rb) -> uint32_t {
-        const int64_t j = rb * 16 + x16;
-        if (a.Ji >= a.J) return (uint32_t)((j * a.s_j + (int64_t)kq * a.s_k) * 8);
-        const uint32_t jo = (uint32_t)j / (uint32_t)a.Ji, ji = (uint32_t)j - jo * (uint32_t)a.Ji;
-        return (uint32_t)(((int64_t)jo * a.s_jo + (int64_t)ji * a.s_j + (int64_t)kq * a.s_k) * 8);
+        int64_t in_off;
+        const int64_t j = row_of(rb, x16, in_off);
+        return j >= 0 ? (uint32_t)((in_off + (int64_t)kq * a.s_k) * 8) : OOB_OFF;
     };
     // masked lanes (k >= K, group past the end) read offset OOB_OFF = 0.0
     auto fetch = [&](uint32_t base, int nkb, int kb) -> double {
-        return ld8(rs, kb < nkb ? base : OOB_OFF, (uint32_t)kb * kstep);
+        return ld8(rs, (kb < nkb && base != OOB_OFF) ? base : OOB_OFF, (uint32_t)kb * kstep);
     };
 
-    int g = blockIdx.x;
+    int g = wg;
     int nkb = g < a.groups ? nkb_lane : 0;
     uint32_t voA = lane_off((int64_t)g * RB + v), voB = lane_off((int64_t)g * RB + 4);
     double ringA[D], ringB[D];
@@ -85,8 +153,9 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
         if (SH) ringB[d] = fetch(voB, sh_on ? nkb : 0, d);
     }
 
+    skinny_s_stage<NPT, D>(a, const_cast<double *>(Wl));   // after the ring loads: both round trips overlap
     SK_STAMP(1);
-    __syncthreads();   // W staged by the caller's loads; every wave reaches this exactly once
+    __syncthreads();   // every wave reaches this exactly once
     SK_STAMP(2);
 
     const double *wl_lane = Wl + kq * LDW + x16 + 16 * tile0;
@@ -100,7 +169,7 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
 #pragma unroll
     for (int t = 0; t < 4; ++t) accB[t] = 0.0;
 
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.C, a.c_extent * 8);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(uniform_ptr(a.C[prob]), a.c_extent * 8);
     // acc[t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is D[4 beta + i][4((beta+t)&3) + j4]
     const int e_m = 4 * ((lane >> 2) & 3) + (lane >> 4);
     int e_j[4];
@@ -111,69 +180,61 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     while (g < a.groups) {
         uint32_t nA = voA, nB = voB;
         int nkb_n = nkb;
-        auto kblock = [&](int it, int itn, int d) {
-            const int kb = it * D + d;
-            const double *wk = wl_lane + kb * 4 * LDW;
-            double af[NTC], as = 0.0;
-#pragma unroll
-            for (int p = 0; p < NT; ++p) af[p] = wk[16 * p];
-            if (SH) as = wk[soffS];
-            double rA[4], rB[4];
-            if (NT) {
-                rot4(ringA[d], rA);
-                ringA[d] = fetch(nA, nkb_n, itn * D + d);
+        // K is padded to ITER * D k-blocks (zero rows of W, masked loads of S): one loop shape for
+        // every iteration keeps the k-blocks overlapping across the whole group
+        for (int it = 0; it < ITER; ++it) {
+            int itn = it + 1;
+            if (itn == ITER) {
+                itn = 0;
+                const int gn = g + a.wpp;
+                nA = lane_off((int64_t)gn * RB + v);
+                nB = lane_off((int64_t)gn * RB + 4);
+                nkb_n = gn < a.groups ? nkb_lane : 0;
             }
-            if (SH) {
-                rot4(ringB[d], rB);
-                ringB[d] = fetch(nB, sh_on ? nkb_n : 0, itn * D + d);
-            }
-#pragma unroll
-            for (int p = 0; p < NT; ++p)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) accA[p][t] = mfma4(af[p], rA[t], accA[p][t]);
-            if (SH) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) accB[t] = mfma4(as, rB[t], accB[t]);
-            }
-        };
-        for (int it = 0; it < ITER - 1; ++it) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) kblock(it, it + 1, d);
-        }
-        {
-            // last iteration of the group: its loads are the next group's first k-blocks; k-blocks
-            // past K (ring slots padded to a multiple of D) are loaded as zeros and not multiplied
-            const int gn = g + gridDim.x;
-            nA = lane_off((int64_t)gn * RB + v);
-            nB = lane_off((int64_t)gn * RB + 4);
-            nkb_n = gn < a.groups ? nkb_lane : 0;
-            const int last = KB - (ITER - 1) * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (d < last) {
-                    kblock(ITER - 1, 0, d);
-                } else {
-                    if (NT) ringA[d] = fetch(nA, nkb_n, d);
-                    if (SH) ringB[d] = fetch(nB, sh_on ? nkb_n : 0, d);
+                const int kb = it * D + d;
+                const double *wk = wl_lane + kb * 4 * LDW;
+                double af[NTC], as = 0.0;
+#pragma unroll
+                for (int p = 0; p < NT; ++p) af[p] = wk[16 * p];
+                if (SH) as = wk[soffS];
+                double rA[4], rB[4];
+                if (NT) {
+                    rot4(ringA[d], rA);
+                    ringA[d] = fetch(nA, nkb_n, itn * D + d);
+                }
+                if (SH) {
+                    rot4(ringB[d], rB);
+                    ringB[d] = fetch(nB, sh_on ? nkb_n : 0, itn * D + d);
+                }
+#pragma unroll
+                for (int p = 0; p < NT; ++p)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accA[p][t] = mfma4(af[p], rA[t], accA[p][t]);
+                if (SH) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accB[t] = mfma4(as, rB[t], accB[t]);
                 }
             }
         }
         SK_STAMP(3);
         // epilogue: branch-free buffer stores, masked lanes go out of range
         {
-            const int64_t jA = ((int64_t)g * RB + v) * 16, jB = ((int64_t)g * RB + 4) * 16;
             uint32_t offs[NTC][4], offt[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int64_t ja = jA + e_j[t], jb = jB + e_j[t];
+                int64_t dummy;
+                const int64_t ja = row_of((int64_t)g * RB + v, e_j[t], dummy);
+                const int64_t jb = row_of((int64_t)g * RB + 4, e_j[t], dummy);
                 const uint32_t oa = (uint32_t)((ja * a.c_j + (int64_t)e_m * a.c_m) * 8);
                 const uint32_t ob = (uint32_t)((jb * a.c_j + (int64_t)e_m * a.c_m) * 8);
 #pragma unroll
                 for (int p = 0; p < NT; ++p) {
-                    offs[p][t] = (ja < a.J && 16 * (tile0 + p) + e_m < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
+                    offs[p][t] = (ja >= 0 && 16 * (tile0 + p) + e_m < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
                     accA[p][t] *= a.alpha;
                 }
-                offt[t] = (sh_on && jb < a.J && 16 * tshared + e_m < a.P) ? ob + tshared * tile_step : OOB_OFF;
+                offt[t] = (sh_on && jb >= 0 && 16 * tshared + e_m < a.P) ? ob + tshared * tile_step : OOB_OFF;
                 accB[t] *= a.alpha;
             }
             if (a.accumulate) {
@@ -211,7 +272,7 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
             }
         }
         SK_STAMP(4);
-        g += gridDim.x;
+        g += a.wpp;
         voA = nA;
         voB = nB;
         nkb = nkb_n;
@@ -227,44 +288,9 @@ template <int NPT, bool SH, int D>
 __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 {
     extern __shared__ double Wl[];
-    constexpr int LDW = ldmf(16 * NPT);
     const int tid = threadIdx.x;
     SK_STAMP(0);
     SK_STAMP_RT(6);
-    // stage W once: Wl[k][m], zero beyond (K, P).  All loads of a thread are issued before the first
-    // LDS store (one memory round trip); masked elements read out of range = 0.  The streamed
-    // operand's first ring loads are issued by skinny_s_wave before it joins the barrier.
-    {
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.W, a.w_extent * 8);
-        const int krows = ((a.K + 3) >> 2) * 4;
-        constexpr int HW = 8 * NPT;                       // pairs per LDS row
-        const int total = krows * HW;
-        const bool vec = a.w_m == 1 && !(a.w_k & 1) && !(a.P & 1) && !((uintptr_t)a.W & 15);
-        constexpr int BATCH = 12;
-        for (int e0 = tid; e0 < total; e0 += 512 * BATCH) {
-            double2 v[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int e = e0 + 512 * u;
-                const int k = e / HW, m = 2 * (e - k * HW);
-                const bool ok = e < total && k < a.K;
-                const uint32_t o0 = (ok && m < a.P) ? (uint32_t)((k * a.w_k + m * a.w_m) * 8) : OOB_OFF;
-                if (vec) {
-                    v[u] = ld16(rw, o0, 0);
-                } else {
-                    const uint32_t o1 = (ok && m + 1 < a.P) ? (uint32_t)((k * a.w_k + (m + 1) * a.w_m) * 8) : OOB_OFF;
-                    v[u].x = ld8(rw, o0, 0);
-                    v[u].y = ld8(rw, o1, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int e = e0 + 512 * u;
-                const int k = e / HW, m = 2 * (e - k * HW);
-                if (e < total) *reinterpret_cast<double2 *>(&Wl[k * LDW + m]) = v[u];
-            }
-        }
-    }
     const int w = tid >> 6, v = w & 3;
     constexpr int H0 = (NPT + 1) / 2, H1 = NPT / 2;
     if (w < 4) skinny_s_wave<NPT, H0, SH, D>(a, Wl, v, 0, w);
@@ -282,8 +308,9 @@ __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 // 32-row block, i.e. the fragments of the "even rows" and the "odd rows" tile at once, 256
 // contiguous bytes per kappa.  Partial outputs go to slab[chunk][m][n]; skinny_r_reduce sums them.
 struct SkinnyR {
-    const double *A, *B;
-    double *slab;
+    const double *A[SK_MAXB], *B[SK_MAXB];
+    double *slab;       // [problem][chunk][m][n]
+    int nb, chunks;     // workgroup x serves chunk x % chunks of problem x / chunks
     int64_t a_ko, a_ki, b_ko, b_ki;
     int64_t Ki, K, chunk;
     int64_t a_extent, b_extent;
@@ -305,9 +332,10 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     const int lane = threadIdx.x & 63;
     const int x16 = lane & 15, kq = lane >> 4;
     SK_STAMP(0);
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.A, a.a_extent * 8);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.B, a.b_extent * 8);
-    const int64_t k0 = (int64_t)blockIdx.x * a.chunk;
+    const int prob = blockIdx.x / a.chunks, ci = blockIdx.x - prob * a.chunks;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(uniform_ptr(a.A[prob]), a.a_extent * 8);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(uniform_ptr(a.B[prob]), a.b_extent * 8);
+    const int64_t k0 = (int64_t)ci * a.chunk;
     const int64_t len = a.K - k0 < a.chunk ? a.K - k0 : a.chunk;
     const int nkb_lane = (int)((len - kq + 3) >> 2);
     const int KB = (int)((len + 3) >> 2);
@@ -448,5 +476,8 @@ __global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
 // 1 = launched, 0 = shape not covered (caller falls through to the generic kernel), < 0 = error
 int skinny_try(const ttsk_gemm_desc &d, const double *A, const double *B, double *C, const double *k_scale,
                int stream, hipStream_t st);
+// the same product for nb <= SK_MAXB problems of one shape (the tensors of a batch) in one launch
+int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, const double *const *B,
+                     double *const *C, int stream, hipStream_t st);
 
 }  // namespace ttsk

@@ -4,7 +4,6 @@
 #include <vector>
 #include "common.h"
 #include "skinny.h"
-#include "tt_step.h"
 
 namespace ttsk {
 
@@ -30,7 +29,7 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     else g_kname_flops[g_cls] = flops;
     if (family < 0) {
     } else if (family == 3)        // streamed x small: tiles = column tiles of the small operand, ak = shared fifth block
-        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %s, 5>", tiles, ak ? "true" : "false");
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %s, %d>", tiles, ak ? "true" : "false", bk ? 4 : 5);
     else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_r_kernel<%d, %d, 4>", tiles / 10, tiles % 10);
     else
@@ -78,22 +77,42 @@ static int gemm(int cls, int64_t M, int64_t N, int64_t Ko, int64_t Ki, const dou
     return rc;
 }
 
-// Right-chain GEMM1 in the layout the long-K kernel wants, T[q][k][p''] (p'' contiguous):
-// a product batched over k whose batch index joins the streamed index.  1 = launched by the
-// streamed-x-small kernel, 0 = shape not covered (caller uses the generic layout), < 0 = error.
-static int right_gemm1_batched(int cls, int64_t rho, int64_t sn, int64_t nn, int64_t sp, const double *Rc,
-                               const double *X, double *T, int stream, hipStream_t st)
+// One product for every tensor of a batch: the chain kernels take all nb problems in one launch
+// (skinny_try_batch); shapes they do not cover fall back to one ttsk_gemm per tensor.
+struct BatchPtrs {
+    const double *A[SK_MAXB], *B[SK_MAXB];
+    double *C[SK_MAXB];
+};
+
+static int gemm_batch(int cls, int nb, ttsk_gemm_desc d, const BatchPtrs &p, int stream, hipStream_t st,
+                      bool chain_only = false)
+{
+    g_cls = cls;
+    ttsk_gemm_desc n = d;
+    if (n.Ki == 1) { n.Ki = n.Ko; n.Ko = 1; n.a_ki = n.a_ko; n.b_ki = n.b_ko; }
+    else if (n.Ko > 1 && n.a_ko == n.Ki * n.a_ki && n.b_ko == n.Ki * n.b_ki) { n.Ki *= n.Ko; n.Ko = 1; }
+    int rc = skinny_try_batch(n, nb, p.A, p.B, p.C, stream, st);
+    if (rc == 0 && !chain_only) {
+        rc = 1;
+        for (int b = 0; b < nb && rc == 1; ++b) {
+            const int e = ttsk_gemm(&d, p.A[b], p.B[b], p.C[b], nullptr, stream);
+            if (e != TTSK_OK) rc = e;
+        }
+    }
+    g_cls = NCLS - 1;
+    return rc;   // 1 = done, 0 = not covered (chain_only), < 0 = error
+}
+
+static ttsk_gemm_desc desc2(int64_t M, int64_t N, int64_t Ko, int64_t Ki, int64_t a_m, int64_t a_ko, int64_t a_ki,
+                            int64_t b_ko, int64_t b_ki, int64_t b_n, int64_t c_m, int64_t c_n, int accumulate)
 {
     ttsk_gemm_desc d{};
-    d.batch = nn; d.M = rho; d.N = sn; d.Ko = 1; d.Ki = sp;
-    d.a_b = 0; d.a_m = 1; d.a_ko = 0; d.a_ki = rho;
-    d.b_b = sp; d.b_ko = 0; d.b_ki = 1; d.b_n = nn * sp;
-    d.c_b = sn; d.c_m = nn * sn; d.c_n = 1;
-    d.alpha = 1.0; d.accumulate = 0; d.split_k = 0;
-    g_cls = cls;
-    const int rc = skinny_try(d, Rc, X, T, nullptr, stream, st);
-    g_cls = NCLS - 1;
-    return rc;
+    d.batch = 1; d.M = M; d.N = N; d.Ko = Ko; d.Ki = Ki;
+    d.a_m = a_m; d.a_ko = a_ko; d.a_ki = a_ki;
+    d.b_ko = b_ko; d.b_ki = b_ki; d.b_n = b_n;
+    d.c_m = c_m; d.c_n = c_n;
+    d.alpha = 1.0; d.accumulate = accumulate; d.split_k = 0;
+    return d;
 }
 
 }  // namespace ttsk
@@ -150,7 +169,16 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
                    const double *const *X, const double *const *DL, const double *const *DR, double *out,
                    int accumulate, int stream)
 {
+    return ttsk_tt_sketch_batch(1, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X, DL, DR, out, 0, accumulate, stream);
+}
+
+int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                         const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                         const double *const *X, const double *const *DL, const double *const *DR, double *out,
+                         int64_t out_stride, int accumulate, int stream)
+{
     TTSK_STREAM(st, stream);
+    TTSK_ARG(nb >= 1, "ttsk_tt_sketch_batch: need nb >= 1, got %d", nb);
     TTSK_ARG(d >= 2, "ttsk_tt_sketch: need d >= 2, got %d", d);
     TTSK_ARG(n && s && lt && l_lo && l_hi && rt && r_lo && r_hi && X && DL && DR && out,
              "ttsk_tt_sketch: NULL argument");
@@ -161,17 +189,29 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         TTSK_ARG(0 <= r_lo[mu] && r_lo[mu] <= r_hi[mu] && r_hi[mu] <= rt[mu + 1],
                  "ttsk_tt_sketch: right rank slice %d out of range", mu);
     }
+    const int64_t one = ttsk_tt_sketch_size(d, n, l_lo, l_hi, r_lo, r_hi);
+    TTSK_ARG(nb == 1 || out_stride >= one, "ttsk_tt_sketch_batch: out_stride %lld < sketch size %lld",
+             (long long)out_stride, (long long)one);
+    if (nb > SK_MAXB) {   // larger batches in slices of SK_MAXB tensors
+        for (int b0 = 0; b0 < nb; b0 += SK_MAXB) {
+            const int cnt = nb - b0 < SK_MAXB ? nb - b0 : SK_MAXB;
+            int rc = ttsk_tt_sketch_batch(cnt, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X + (size_t)b0 * d, DL, DR,
+                                          out + (size_t)b0 * out_stride, out_stride, accumulate, stream);
+            if (rc) return rc;
+        }
+        return TTSK_OK;
+    }
     // The right chain runs on the caller's stream, the left chain on a helper stream (the two are
     // independent until Psi / Omega need both); the Psi products are then dealt over both.  The
     // helper is forked from / joined into `stream`, so callers (and hipGraph capture) see one stream.
-    // TTSK_SINGLE_STREAM=1 (or an active profiling pass) keeps everything on `stream`: per-kernel event
-    // times are then free of cross-stream sharing and match rocprofv3's kernel durations.
+    // TTSK_SINGLE_STREAM=1 keeps everything on `stream`: per-kernel event times are then free of
+    // cross-stream sharing and match rocprofv3's kernel durations (bench.py roofline leg).
     const char *single = getenv("TTSK_SINGLE_STREAM");
     const int aux = (single && single[0] == '1') ? stream : (stream + 1) % TTSK_NUM_STREAMS;
     TTSK_STREAM(st_aux, aux);
-    (void)st_aux;
-    // workspace (per stream slot DRIVER of `stream`): Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]),
-    // one T buffer per left mode (kept for the Psi phase) and one T buffer for the right chain
+    // workspace of one tensor (slot DRIVER of `stream`, tensor b at ws + b * tot):
+    // Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]), one T buffer per left mode (kept for
+    // the Psi phase) and one T buffer for the right chain
     size_t tot = 0;
     std::vector<size_t> offL(d - 1), offR(d - 1), offT(d);
     for (int mu = 0; mu < d - 1; ++mu) { offL[mu] = tot; tot += (size_t)s[mu + 1] * lt[mu + 1]; }
@@ -184,158 +224,82 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
     }
     const size_t offTR = tot;
     tot += tr_max;
-    double *ws = (double *)scratch(stream, SCRATCH_DRIVER, tot * 8);
-    if (!ws) return TTSK_ERR_HIP;
+    tot = (tot + 31) & ~(size_t)31;   // 256-byte aligned per-tensor blocks (16-byte operand loads)
+    double *ws0 = (double *)scratch(stream, SCRATCH_DRIVER, (size_t)nb * tot * 8);
+    if (!ws0) return TTSK_ERR_HIP;
+    auto ws = [&](int b) { return ws0 + (size_t)b * tot; };
+    auto Xc = [&](int b, int mu) { return X[(size_t)b * d + mu]; };
+    auto outb = [&](int b) { return out + (size_t)b * out_stride; };
     int rc;
-#define CK(x) do { rc = (x); if (rc) return rc; } while (0)
-    // ---- fused schedule: every interior chain step is ONE kernel (tt_step.hip) + the slab sum.
-    // The left steps carry Psi and therefore need R_mu, which the right chain produces last-to-first:
-    // the right chain runs to completion first, then the left chain; the small products (first /
-    // last mode, Omega) go to the helper stream.
-    // Measured at the bench workload: 42 us per fused step; the sequential right-then-left schedule
-    // it needs totals 0.51 ms per sketch against 0.41 ms for the two-stream GEMM schedule below, so
-    // the fused step is opt-in (TTSK_FUSED_STEP=1) until its MFMA duty improves.
-    const char *fenv = getenv("TTSK_FUSED_STEP");
-    bool fuse = fenv != nullptr && fenv[0] == '1';
-    for (int mu = 1; mu < d - 1 && fuse; ++mu) {
-        const int j = d - 1 - mu;
-        fuse = tt_step_fits(s[mu + 1], s[mu], rt[j], rt[j + 1], 0, 0, (int64_t)SMAX_ROWS * n[mu] * s[mu + 1]) &&
-               tt_step_fits(s[mu], s[mu + 1], lt[mu], lt[mu + 1], r_hi[d - 2 - mu] - r_lo[d - 2 - mu],
-                            l_hi[mu - 1] - l_lo[mu - 1], (int64_t)(s[mu] + 32) * n[mu] * s[mu + 1]);
-    }
-    if (fuse) {
-        std::vector<double *> psi_at(d), om_at(d - 1);
-        {
-            double *p = out;
-            for (int mu = 0; mu < d; ++mu) {
-                int64_t l = mu == 0 ? 1 : l_hi[mu - 1] - l_lo[mu - 1];
-                int64_t r = mu == d - 1 ? 1 : r_hi[d - 2 - mu] - r_lo[d - 2 - mu];
-                psi_at[mu] = p;
-                p += l * n[mu] * r;
-            }
-            for (int mu = 0; mu < d - 1; ++mu) {
-                om_at[mu] = p;
-                p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
-            }
-        }
-        CK(ttsk_stream_wait(aux, stream));   // fork
-        // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q'] on the helper stream (independent of the right chain)
-        CK(gemm(5, s[1], lt[1], 1, n[0], X[0], 1, 0, s[1], DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
-        // right chain
-        for (int j = 0; j < d - 1; ++j) {
-            const int mu = d - 1 - j;
-            const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
-            double *Rn = ws + offR[j];
-            if (j == 0) {
-                CK(gemm(5, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
-                continue;
-            }
-            StepArgs g{};
-            g.s_in = (int)sp; g.s_out = (int)sn; g.rho = (int)rho; g.rhop = (int)rhop; g.r = 0;
-            g.x_k = sp; g.x_a = nn * sp; g.x_b = 1; g.x_extent = sn * nn * sp;
-            g.X = X[mu]; g.Cin = ws + offR[j - 1]; g.ldc = rho; g.c_extent = sp * rho;
-            g.D = DR[j]; g.d_q = nn * rhop; g.d_k = rhop; g.d_extent = rho * nn * rhop;
-            CK(tt_step_launch(true, nn, g, Rn, rhop, stream));
-        }
-        CK(ttsk_stream_wait(stream, aux));   // L_0 ready
-        // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c] and Omega_0 on the helper stream
-        CK(ttsk_stream_wait(aux, stream));   // right chain complete
-        {
-            const int jr = d - 2;
-            const double *Rm = ws + offR[jr] + r_lo[jr];
-            const int64_t ldr = rt[jr + 1], r = r_hi[jr] - r_lo[jr];
-            CK(gemm(5, n[0], r, 1, s[1], X[0], s[1], 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, aux));
-            CK(gemm(5, l_hi[0] - l_lo[0], r, 1, s[1], ws + offL[0] + l_lo[0], 1, 0, lt[1], Rm, 0, ldr, 1, om_at[0],
-                    r, 1, accumulate, aux));
-        }
-        // left chain with Psi
-        for (int mu = 1; mu < d; ++mu) {
-            const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu], lfull = lt[mu];
-            const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
-            const double *Lc = ws + offL[mu - 1];
-            if (mu == d - 1) {
-                // last mode: Psi_{d-1}[q,k,0] = sum_p L[p, lo+q] X[p,k,0]
-                CK(gemm(5, l, nn, 1, sn, Lc + l_lo[mu - 1], 1, 0, lfull, X[mu], 0, nn * sp, 1, psi_at[mu], nn, 1,
-                        accumulate, stream));
-                break;
-            }
-            const int jr = d - 2 - mu;
-            const double *Rm = ws + offR[jr] + r_lo[jr];
-            const int64_t ldr = rt[jr + 1], r = r_hi[jr] - r_lo[jr];
-            StepArgs g{};
-            g.s_in = (int)sn; g.s_out = (int)sp; g.rho = (int)lfull; g.rhop = (int)lt[mu + 1]; g.r = (int)r;
-            g.q_lo = (int)l_lo[mu - 1]; g.q_cnt = (int)l; g.accumulate_psi = accumulate;
-            g.x_k = sp; g.x_a = 1; g.x_b = nn * sp; g.x_extent = sn * nn * sp;
-            g.X = X[mu]; g.Cin = Lc; g.ldc = lfull; g.c_extent = sn * lfull;
-            g.D = DL[mu]; g.d_q = nn * lt[mu + 1]; g.d_k = lt[mu + 1]; g.d_extent = lfull * nn * lt[mu + 1];
-            g.R = Rm; g.ldr = ldr; g.r_extent = (sp - 1) * ldr + r;
-            g.Psi = psi_at[mu]; g.psi_q = nn * r; g.psi_k = r; g.psi_c = 1;
-            CK(tt_step_launch(false, nn, g, ws + offL[mu], lt[mu + 1], stream));
-            // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi] on the helper stream
-            CK(ttsk_stream_wait(aux, stream));
-            CK(gemm(5, l_hi[mu] - l_lo[mu], r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1,
-                    om_at[mu], r, 1, accumulate, aux));
-        }
-        CK(ttsk_stream_wait(stream, aux));   // join
-        return TTSK_OK;
-    }
+#define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
     CK(ttsk_stream_wait(aux, stream));   // fork
 
     // ---- right chain (stream): walks modes d-1, ..., 1 on the transposed tensor (views only).
     // Xt_j[p,k,p''] = X_mu[p'',k,p], mu = d-1-j.
-    {
-        double *T = ws + offTR;
-        for (int j = 0; j < d - 1; ++j) {
-            const int mu = d - 1 - j;
-            const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
-            double *Rn = ws + offR[j];
-            if (j == 0) {
-                // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
-                CK(gemm(5, sn, rhop, 1, nn, X[mu], nn * sp, 0, sp, DR[j], 0, rhop, 1, Rn, rhop, 1, 0, stream));
-            } else {
-                const double *Rc = ws + offR[j - 1];                   // (sp x rho)
-                // preferred: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (batched over k), so that both
-                // operands of GEMM2 are contiguous along their output index
-                const int fast = right_gemm1_batched(0, rho, sn, nn, sp, Rc, X[mu], T, stream, st);
-                if (fast < 0) return fast;
-                if (fast == 1) {
-                    // Rn[p'', q'] = sum_{q,k} T[q,k,p''] E[q,k,q']
-                    CK(gemm(1, sn, rhop, rho, nn, T, 1, nn * sn, sn, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
-                } else {
-                    // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
-                    CK(gemm(0, rho, sn * nn, 1, sp, Rc, 1, 0, rho, X[mu], 0, 1, sp, T, sn * nn, 1, 0, stream));
-                    // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
-                    CK(gemm(1, sn, rhop, rho, nn, T, nn, sn * nn, 1, DR[j], nn * rhop, rhop, 1, Rn, rhop, 1, 0, stream));
-                }
-            }
+    for (int j = 0; j < d - 1; ++j) {
+        const int mu = d - 1 - j;
+        const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
+        BatchPtrs p{};
+        if (j == 0) {
+            // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, mu); p.B[b] = DR[j]; p.C[b] = ws(b) + offR[j]; }
+            CK(gemm_batch(5, nb, desc2(sn, rhop, 1, nn, nn * sp, 0, sp, 0, rhop, 1, rhop, 1, 0), p, stream, st));
+            continue;
+        }
+        // preferred: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (a product batched over k whose batch index
+        // joins the streamed index), so that both operands of GEMM2 are contiguous along their output index
+        for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offR[j - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offTR; }
+        ttsk_gemm_desc g1{};
+        g1.batch = nn; g1.M = rho; g1.N = sn; g1.Ko = 1; g1.Ki = sp;
+        g1.a_b = 0; g1.a_m = 1; g1.a_ki = rho;
+        g1.b_b = sp; g1.b_ki = 1; g1.b_n = nn * sp;
+        g1.c_b = sn; g1.c_m = nn * sn; g1.c_n = 1;
+        g1.alpha = 1.0;
+        const int fast = gemm_batch(0, nb, g1, p, stream, st, true);
+        if (fast < 0) return fast;
+        BatchPtrs q{};
+        for (int b = 0; b < nb; ++b) { q.A[b] = ws(b) + offTR; q.B[b] = DR[j]; q.C[b] = ws(b) + offR[j]; }
+        if (fast == 1) {
+            // Rn[p'', q'] = sum_{q,k} T[q,k,p''] E[q,k,q']
+            CK(gemm_batch(1, nb, desc2(sn, rhop, rho, nn, 1, nn * sn, sn, nn * rhop, rhop, 1, rhop, 1, 0), q, stream, st));
+        } else {
+            // T[q, p'', k] = sum_p Rc[p,q] X[p'',k,p]    (M=q, N=(p'',k), K=p)
+            CK(gemm_batch(0, nb, desc2(rho, sn * nn, 1, sp, 1, 0, rho, 0, 1, sp, sn * nn, 1, 0), p, stream, st));
+            // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
+            CK(gemm_batch(1, nb, desc2(sn, rhop, rho, nn, nn, sn * nn, 1, nn * rhop, rhop, 1, rhop, 1, 0), q, stream, st));
         }
     }
     // ---- left chain (aux): L_mu and the shared products T_mu = L_{mu-1}^T X_mu
     for (int mu = 0; mu < d; ++mu) {
         const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
+        BatchPtrs p{};
         if (mu == 0) {
             // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
-            CK(gemm(5, sp, lt[1], 1, nn, X[0], 1, 0, sp, DL[0], 0, lt[1], 1, ws + offL[0], lt[1], 1, 0, aux));
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = DL[0]; p.C[b] = ws(b) + offL[0]; }
+            CK(gemm_batch(5, nb, desc2(sp, lt[1], 1, nn, 1, 0, sp, 0, lt[1], 1, lt[1], 1, 0), p, aux, st_aux));
             continue;
         }
         const int64_t lfull = lt[mu];
-        const double *Lc = ws + offL[mu - 1];                   // (sn x lfull)
-        double *T = ws + offT[mu];
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
-        CK(gemm(mu == d - 1 ? 5 : 2, lfull, nn * sp, 1, sn, Lc, 1, 0, lfull, X[mu], 0, nn * sp, 1, T, nn * sp, 1, 0, aux));
-        if (mu < d - 1)
+        for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offL[mu - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offT[mu]; }
+        CK(gemm_batch(mu == d - 1 ? 5 : 2, nb, desc2(lfull, nn * sp, 1, sn, 1, 0, lfull, 0, nn * sp, 1, nn * sp, 1, 0), p,
+                      aux, st_aux));
+        if (mu < d - 1) {
             // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
-            CK(gemm(3, sp, lt[mu + 1], 1, lfull * nn, T, 1, 0, sp, DL[mu], 0, lt[mu + 1], 1, ws + offL[mu],
-                    lt[mu + 1], 1, 0, aux));
+            BatchPtrs q{};
+            for (int b = 0; b < nb; ++b) { q.A[b] = ws(b) + offT[mu]; q.B[b] = DL[mu]; q.C[b] = ws(b) + offL[mu]; }
+            CK(gemm_batch(3, nb, desc2(sp, lt[mu + 1], 1, lfull * nn, 1, 0, sp, 0, lt[mu + 1], 1, lt[mu + 1], 1, 0), q,
+                          aux, st_aux));
+        }
     }
     // both chains are needed from here on, on both streams
     CK(ttsk_stream_wait(stream, aux));
     CK(ttsk_stream_wait(aux, stream));
 
     // ---- Psi and Omega, dealt over the two streams
-    std::vector<double *> psi_at(d), om_at(d - 1);
+    std::vector<size_t> psi_at(d), om_at(d - 1);
     {
-        double *p = out;
+        size_t p = 0;
         for (int mu = 0; mu < d; ++mu) {
             int64_t l = mu == 0 ? 1 : l_hi[mu - 1] - l_lo[mu - 1];
             int64_t r = mu == d - 1 ? 1 : r_hi[d - 2 - mu] - r_lo[d - 2 - mu];
@@ -353,28 +317,39 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
         hipStream_t stq = stream_of(q);
         // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
         const int jr = d - 2 - mu;
-        const double *Rm = mu < d - 1 ? ws + offR[jr] + r_lo[jr] : nullptr;
+        const size_t offRm = mu < d - 1 ? offR[jr] + r_lo[jr] : 0;
         const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
+        BatchPtrs p{};
         if (mu == 0) {
             // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c]
-            CK(gemm(5, nn, r, 1, sp, X[0], sp, 0, 1, Rm, 0, ldr, 1, psi_at[0], r, 1, accumulate, q));
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = ws(b) + offRm; p.C[b] = outb(b) + psi_at[0]; }
+            CK(gemm_batch(5, nb, desc2(nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
         } else {
             const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
-            const double *Ts = ws + offT[mu] + l_lo[mu - 1] * nn * sp;   // rows of the rank slice
+            const size_t offTs = offT[mu] + l_lo[mu - 1] * nn * sp;   // rows of the rank slice
             if (mu < d - 1) {
                 // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
-                CK(gemm(4, l * nn, r, 1, sp, Ts, sp, 0, 1, Rm, 0, ldr, 1, psi_at[mu], r, 1, accumulate, q));
+                for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offTs; p.B[b] = ws(b) + offRm; p.C[b] = outb(b) + psi_at[mu]; }
+                CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
             } else {
                 // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
-                if (accumulate) CK(ttsk_axpby(psi_at[mu], Ts, 1.0, 1.0, (size_t)(l * nn), q));
-                else TTSK_HIP(hipMemcpyAsync(psi_at[mu], Ts, (size_t)(l * nn) * 8, hipMemcpyDeviceToDevice, stq));
+                for (int b = 0; b < nb; ++b) {
+                    if (accumulate) CK(ttsk_axpby(outb(b) + psi_at[mu], ws(b) + offTs, 1.0, 1.0, (size_t)(l * nn), q));
+                    else TTSK_HIP(hipMemcpyAsync(outb(b) + psi_at[mu], ws(b) + offTs, (size_t)(l * nn) * 8,
+                                                 hipMemcpyDeviceToDevice, stq));
+                }
             }
         }
         if (mu < d - 1) {
-            // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]
+            // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]; the workspace blocks and the outputs of a
+            // batch are equally spaced, so the nb products are one batched launch
             const int64_t l = l_hi[mu] - l_lo[mu];
-            CK(gemm(5, l, r, 1, sp, ws + offL[mu] + l_lo[mu], 1, 0, lt[mu + 1], Rm, 0, ldr, 1, om_at[mu], r, 1,
-                    accumulate, q));
+            ttsk_gemm_desc od = desc2(l, r, 1, sp, 1, 0, lt[mu + 1], 0, ldr, 1, r, 1, accumulate);
+            od.batch = nb; od.a_b = (int64_t)tot; od.b_b = (int64_t)tot; od.c_b = out_stride;
+            g_cls = 5;
+            rc = ttsk_gemm(&od, ws(0) + offL[mu] + l_lo[mu], ws(0) + offRm, outb(0) + om_at[mu], nullptr, q);
+            g_cls = NCLS - 1;
+            if (rc) return rc;
         }
     }
     CK(ttsk_stream_wait(stream, aux));   // join

@@ -68,6 +68,13 @@ class TTSketchPlan:
                  self.r_lo, self.r_hi, X_ptrs, self.DL, self.DR, ctypes.c_void_p(out.ptr),
                  1 if accumulate else 0, stream)
 
+    def run_batch(self, X_ptrs, nb: int, out: DevArray, out_stride: int, accumulate: bool = False, stream: int = 0):
+        """``nb`` tensors of the plan's signature in one pass: ``X_ptrs`` holds nb * d core pointers
+        (tensor-major), sketch ``b`` lands at ``out[b * out_stride:]``."""
+        nat.call("ttsk_tt_sketch_batch", nb, self.d, self.n, self.s, self.lt, self.l_lo, self.l_hi, self.rt,
+                 self.r_lo, self.r_hi, X_ptrs, self.DL, self.DR, ctypes.c_void_p(out.ptr),
+                 _I64(out_stride), 1 if accumulate else 0, stream)
+
     def views(self, out: DevArray) -> Tuple[List[DevArray], List[DevArray]]:
         """Psi / Omega arrays as views into the packed buffer."""
         d, off = self.d, 0
