@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--batch", type=int, default=1, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
+    ap.add_argument("--batch", type=int, default=4, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent sketches in flight (items of the tensor stream are issued on alternating "
@@ -222,6 +222,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    # latency of ONE sketch issued alone (batch 1, nothing else in flight), for reference
+    single_ms = None
+    if world == 1:
+        one = (ctypes.c_void_p * plan.d)(*[ptrs[i] for i in range(plan.d)])
+        for _ in range(3):
+            plan.run(one, out)
+        nat.call("ttsk_sync", -1)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            plan.run(one, out)
+        nat.call("ttsk_sync", -1)
+        single_ms = 1e3 * (time.perf_counter() - t1) / 20
+        run_on(0)                      # restore the batched result checked below
+        nat.call("ttsk_sync", -1)
+
     result = None
     if rank == 0:
         fl = algorithmic_flops(shape, (S_IN,) * (D - 1), (L_RANK,) * (D - 1), (R_RANK,) * (D - 1))
@@ -288,7 +303,7 @@ def main():
                                            ("; partial sketches summed by one RCCL all-reduce" if world > 1 else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
-                                  tts_per_step=B, steps_in_flight=inflight,
+                                  tts_per_step=B, steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
                                   sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
         print(json.dumps(result))

@@ -183,7 +183,8 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
         ttsk_gemm_desc n = d;
         if (n.Ki == 1) { n.Ki = n.Ko; n.Ko = 1; n.a_ki = n.a_ko; n.b_ki = n.b_ko; }
         else if (n.Ko > 1 && n.a_ko == n.Ki * n.a_ki && n.b_ko == n.Ki * n.b_ki) { n.Ki *= n.Ko; n.Ko = 1; }
-        const int rs = skinny_try(n, A, B, C, k_scale, stream, st);
+        int rs = skinny_try(n, A, B, C, k_scale, stream, st);
+        if (rs == 0 && !k_scale) rs = small_try_batch(n, 1, &A, &B, &C, stream, st);
         if (rs < 0) return rs;
         if (rs == 1) return TTSK_OK;
     }

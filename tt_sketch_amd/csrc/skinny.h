@@ -27,8 +27,10 @@ struct SkinnyS {
     int64_t w_k, w_m;   // W[k][m]
     int64_t s_j, s_k;   // S[j][k]
     // Two-level streamed index j = u V + v (u < U at stride s_u, v < V at stride s_j; U = 1: plain).
-    // A 16-row block is then a (16 >> tvl) (u) x (1 << tvl) (v) tile, tvl = 2, 3 or 4: the right
-    // chain's GEMM1 reads X[p'', k, :] for a few consecutive k of a few p'' and writes T[q][k][p''].
+    // A 16-row block is then a (16 >> tvl) (u) x (1 << tvl) (v) tile.  tvl = 4 (16 consecutive v of
+    // one u: the right chain's GEMM1 reads X[p'', k, :] for 16 p'' of one k and writes whole 128-byte
+    // lines of T[q][k][p'']) measured best; 4 x 4 and 2 x 8 tiles read longer runs but write
+    // 32- / 64-byte pieces and were 5-10 % slower end to end.
     int64_t s_u;
     int U, V, nbv, tvl;
     int64_t c_m, c_j;   // C[m][j]
@@ -476,6 +478,9 @@ __global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
 // 1 = launched, 0 = shape not covered (caller falls through to the generic kernel), < 0 = error
 int skinny_try(const ttsk_gemm_desc &d, const double *A, const double *B, double *C, const double *k_scale,
                int stream, hipStream_t st);
+// small products (small.hip): nb pointer triples, or one triple with a uniformly strided d.batch
+int small_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, const double *const *B, double *const *C,
+                    int stream, hipStream_t st);
 // the same product for nb <= SK_MAXB problems of one shape (the tensors of a batch) in one launch
 int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, const double *const *B,
                      double *const *C, int stream, hipStream_t st);

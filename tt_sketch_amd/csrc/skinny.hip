@@ -87,6 +87,8 @@ static int run_s(SkinnyS a, hipStream_t st, int *prof, double flops)
     a.groups = (int)groups;
     const int ldw = ldmf(16 * npt);
     // ring depth 5 unless 4 pads K less (k-blocks are processed in multiples of the depth)
+    // (a second, register-free prefetch level through `buffer_load ... lds`, a ring as deep as the
+    // whole K and opposite k orders for the two waves of a SIMD were all measured slower)
     const int dring = cdiv(kb, 5) * 5 <= cdiv(kb, 4) * 4 ? 5 : 4;
     const size_t lds = (size_t)cdiv(kb, dring) * dring * 4 * ldw * 8;
     a.wpp = (int)(groups < cus ? groups : cus);
@@ -204,7 +206,7 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     s.J = d.batch * (int64_t)s.V;
     s.U = (int)d.batch;
     if (d.batch == 1) s.s_u = 0;
-    { const char *e = getenv("TTSK_S_TVL"); s.tvl = e ? atoi(e) : 4; }
+    s.tvl = 4;
     s.nbv = (int)cdiv(s.V, 1 << s.tvl);
     if (s.s_j < 0 || s.s_k < 0 || s.s_u < 0 || s.w_k < 0 || s.w_m < 0 || s.c_m < 0 || s.c_j < 0) return 0;
     if (s.J >= (1ll << 31) - 256) return 0;
@@ -220,7 +222,7 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     const int64_t reach_c = ((s.J + 96) * s.c_j + 144 * s.c_m) * 8;
     if (reach >= (1ll << 32) - 64 || reach_c >= (1ll << 32) - 64 || s.w_extent * 8 >= (1ll << 31)) return 0;
     const int npt = (int)cdiv(s.P, 16);
-    if ((size_t)((cdiv(K, 4) + 4) * 4 * ldmf(16 * npt) + 16) * 8 > 160 * 1024) return 0;
+    if ((size_t)((cdiv(K, 4) + 4) * 4 * ldmf(16 * npt) + 16) * 8 + 2048 > 160 * 1024) return 0;
     const bool prof = prof_on();
     int sh = 0;
     int rc = run_s(s, st, prof ? &sh : nullptr, 2.0 * nb * (double)d.batch * (double)d.M * (double)d.N * (double)K);

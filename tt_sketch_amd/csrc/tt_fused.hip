@@ -30,6 +30,8 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     if (family < 0) {
     } else if (family == 3)        // streamed x small: tiles = column tiles of the small operand, ak = shared fifth block
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %s, %d>", tiles, ak ? "true" : "false", bk ? 4 : 5);
+    else if (family == 5)
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "small_gemm_kernel");
     else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_r_kernel<%d, %d, 4>", tiles / 10, tiles % 10);
     else
@@ -92,6 +94,7 @@ static int gemm_batch(int cls, int nb, ttsk_gemm_desc d, const BatchPtrs &p, int
     if (n.Ki == 1) { n.Ki = n.Ko; n.Ko = 1; n.a_ki = n.a_ko; n.b_ki = n.b_ko; }
     else if (n.Ko > 1 && n.a_ko == n.Ki * n.a_ki && n.b_ko == n.Ki * n.b_ki) { n.Ki *= n.Ko; n.Ko = 1; }
     int rc = skinny_try_batch(n, nb, p.A, p.B, p.C, stream, st);
+    if (rc == 0 && !chain_only) rc = small_try_batch(n, nb, p.A, p.B, p.C, stream, st);
     if (rc == 0 && !chain_only) {
         rc = 1;
         for (int b = 0; b < nb && rc == 1; ++b) {

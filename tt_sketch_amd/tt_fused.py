@@ -19,6 +19,7 @@ from .drm.tensor_train_drm import TensorTrainDRM
 from .tensor import TensorSum, TensorTrain
 
 _I64 = ctypes.c_int64
+MAX_BATCH = 8   # tensors per batched pass (SK_MAXB in csrc/skinny.h)
 
 
 class TTSketchPlan:
@@ -110,11 +111,32 @@ def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[lis
         return None
     if tuple(left_drm.shape) != tuple(tensor.shape) or tuple(right_drm.shape) != tuple(tensor.shape):
         raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensor.shape}")
-    out = None
-    for k, tt in enumerate(terms):
-        plan = TTSketchPlan(tt.shape, tt.rank, left_drm, right_drm)
+    # Terms of one signature (mode sizes, TT ranks) go through the device in batches: every chain
+    # product is then one launch over the whole batch (ttsk_tt_sketch_batch) and the partial
+    # sketches are summed afterwards -- the TensorSum loop of sketch_dispatch.py:85-139.
+    from .device import axpby
+    groups = {}
+    for tt in terms:
+        groups.setdefault((tuple(tt.shape), tuple(tt.rank)), []).append(tt)
+    out, plan0 = None, None
+    for (shape, rank), tts in groups.items():
+        plan = TTSketchPlan(shape, rank, left_drm, right_drm)
+        plan0 = plan0 or plan
         if out is None:
-            out = plan.new_buffer()
-        ptrs, keep = plan.core_pointers(tt)
-        plan.run(ptrs, out, accumulate=k > 0)
-    return plan.views(out)
+            out = DevArray.zeros((plan.size,))
+        for b0 in range(0, len(tts), MAX_BATCH):
+            chunk = tts[b0:b0 + MAX_BATCH]
+            if len(chunk) == 1:
+                ptrs, keep = plan.core_pointers(chunk[0])
+                plan.run(ptrs, out, accumulate=True)
+                continue
+            keep, flat = [], []
+            for tt in chunk:
+                ptrs, k = plan.core_pointers(tt)
+                keep.append(k)
+                flat += [ptrs[i] for i in range(plan.d)]
+            tmp = DevArray.empty((len(chunk) * plan.size,))
+            plan.run_batch((ctypes.c_void_p * len(flat))(*flat), len(chunk), tmp, plan.size)
+            for b in range(len(chunk)):
+                axpby(out, tmp[b * plan.size:(b + 1) * plan.size], 1.0, 1.0)
+    return plan0.views(out)
