@@ -107,12 +107,11 @@ __device__ __forceinline__ void skinny_s_stage(const SkinnyS &a, double *Wl)
 // rows: waves v and v+4 share row block 4g+v and split W's NPT column tiles ceil/floor; if SH,
 // the tiles of a fifth block are dealt one per wave.  For C3 (NPT = 7) that is 9,9,9,8 tile
 // strips on the four SIMDs and 1250 row blocks -> 250 workgroups = one round over 256 CUs.
-template <int NPT, int NT, bool SH, int D>
+template <int NPT, int NT, bool SH, int D, int RB>
 __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl, const int v, const int tile0,
                                               const int tshared)
 {
     constexpr int LDW = ldmf(16 * NPT);
-    constexpr int RB = SH ? 5 : 4;
     constexpr int NTC = NT ? NT : 1;
     const int lane = threadIdx.x & 63;
     const int x16 = lane & 15, kq = lane >> 4;
@@ -286,7 +285,14 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     }
 }
 
-template <int NPT, bool SH, int D>
+// MODE 0: groups of 4 row blocks, waves v and v+4 split the tiles of block v.
+// MODE 1: the same plus a fifth block whose tiles are dealt one per wave (fills 256 CUs in one
+//         round at the single-tensor C3 shapes).
+// MODE 2: groups of 8 row blocks, every wave owns one block against all NPT tiles: no fragment is
+//         loaded twice.  The vector memory pipe (one tag lookup per touched line, 16 lines per
+//         k-fast load) is what saturates in these kernels, so this is the mode of choice whenever
+//         the group count still fills the CUs.
+template <int NPT, int MODE, int D>
 __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 {
     extern __shared__ double Wl[];
@@ -295,8 +301,13 @@ __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
     SK_STAMP_RT(6);
     const int w = tid >> 6, v = w & 3;
     constexpr int H0 = (NPT + 1) / 2, H1 = NPT / 2;
-    if (w < 4) skinny_s_wave<NPT, H0, SH, D>(a, Wl, v, 0, w);
-    else       skinny_s_wave<NPT, H1, SH, D>(a, Wl, v, H0, w);
+    if constexpr (MODE == 2) {
+        skinny_s_wave<NPT, NPT, false, D, 8>(a, Wl, w, 0, 0);
+    } else {
+        constexpr bool SH = MODE == 1;
+        if (w < 4) skinny_s_wave<NPT, H0, SH, D, SH ? 5 : 4>(a, Wl, v, 0, w);
+        else       skinny_s_wave<NPT, H1, SH, D, SH ? 5 : 4>(a, Wl, v, H0, w);
+    }
 }
 
 // ---- long-K products -------------------------------------------------------------------

@@ -73,17 +73,21 @@ static int run_s(SkinnyS a, hipStream_t st, int *prof, double flops)
     const int npt = (int)cdiv(a.P, 16);
     const int kb = (a.K + 3) / 4;
     const int64_t nrb = a.U == 1 ? cdiv(a.J, 16) : cdiv(a.U, 16 >> a.tvl) * cdiv(a.V, 1 << a.tvl);
-    const int cus = num_cu();
-    // fifth, shared row block or not: fewer rounds of workgroups over the CUs wins
-    // SIMD s runs waves s and s+4: ceil(npt/2) + floor(npt/2) own tile strips, + 2 shared ones if dealt
-    int spt = 0;
-    {
-        const int64_t g4 = cdiv(nrb, 4), g5 = cdiv(nrb, 5);
-        const int sh_cost = npt > 4 ? 2 : 1;
-        const int64_t t4 = cdiv(g4, cus) * npt, t5 = cdiv(g5, cus) * (npt + sh_cost);
-        if (t5 < t4) spt = 1;
-    }
-    const int64_t groups = cdiv(nrb, spt ? 5 : 4);
+    static int wgdiv = [] { const char *e = getenv("TTSK_S_SPLIT"); return e ? atoi(e) : 1; }();
+    // CUs one problem of the batch can count on (TTSK_S_SPLIT=0: every problem spreads over all CUs)
+    const int cus = (wgdiv && num_cu() / a.nb > 0) ? num_cu() / a.nb : num_cu();
+    // mode (see skinny_s_kernel): rounds of workgroups over the CUs x tile strips per SIMD and round.
+    // Mode 2 loads no fragment twice and measured ~10 % faster at equal strip counts, so the others
+    // have to beat it by more than that; ties between them go to the one without the shared block.
+    static int mode_force = [] { const char *e = getenv("TTSK_S_MODE"); return e ? atoi(e) : -1; }();
+    const int64_t g4 = cdiv(nrb, 4), g5 = cdiv(nrb, 5), g8 = cdiv(nrb, 8);
+    const int64_t t4 = cdiv(g4, cus) * npt, t5 = cdiv(g5, cus) * (npt + (npt > 4 ? 2 : 1)), t8 = cdiv(g8, cus) * 2 * npt;
+    int spt = 2;
+    int64_t best = t8;
+    if (t4 * 112 < best * 100) { best = t4 * 112 / 100; spt = 0; }
+    if (t5 * 112 < best * 100 && t5 < t4) { best = t5 * 112 / 100; spt = 1; }
+    if (mode_force >= 0 && mode_force <= 2) spt = mode_force;
+    const int64_t groups = spt == 2 ? g8 : (spt == 1 ? g5 : g4);
     a.groups = (int)groups;
     const int ldw = ldmf(16 * npt);
     // ring depth 5 unless 4 pads K less (k-blocks are processed in multiples of the depth)
@@ -93,7 +97,7 @@ static int run_s(SkinnyS a, hipStream_t st, int *prof, double flops)
     const size_t lds = (size_t)cdiv(kb, dring) * dring * 4 * ldw * 8;
     a.wpp = (int)(groups < cus ? groups : cus);
     const int grid = a.wpp * a.nb;
-    if (prof) prof_open(st, flops, 3, npt, spt != 0, dring == 4);
+    if (prof) prof_open(st, flops, 3, npt * 10 + spt, false, dring == 4);
     if (dring == 4) return launch_skinny_s_depth<4>(a, npt, spt, lds, grid, st);
     return launch_skinny_s_depth<5>(a, npt, spt, lds, grid, st);
 }
