@@ -161,8 +161,10 @@ def main():
     plan = TTSketchPlan(tt.shape, tt.rank, left, right)
     inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
     from tt_sketch_amd.device import DevArray
-    outs = [DevArray.empty((B * plan.size,)) for _ in range(inflight)]
+    stride = plan.size + (plan.size & 1)            # even spacing keeps every sketch 16-byte aligned
+    outs = [DevArray.empty((B * stride,)) for _ in range(inflight)]
     out = outs[0]
+    sums = [DevArray.empty((plan.size,)) for _ in range(inflight)] if world > 1 else None
     keep, flat = [], []
     for t in tts:
         p1, k1 = plan.core_pointers(t)
@@ -172,14 +174,23 @@ def main():
     counter = [0]
 
     def run_on(slot):
-        plan.run_batch(ptrs, B, outs[slot], plan.size, stream=2 * slot)   # stream pair (2 slot, 2 slot + 1)
+        plan.run_batch(ptrs, B, outs[slot], stride, stream=2 * slot)   # stream pair (2 slot, 2 slot + 1)
 
     def step_eager():
         slot = counter[0] % inflight
         counter[0] += 1
         run_on(slot)
         if world > 1:
-            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(outs[slot].ptr), ctypes.c_size_t(B * plan.size), 2 * slot)
+            # the B partial sketches of this rank are summed locally, then ONE all-reduce of one sketch
+            # (32 MB) per step makes every rank hold the sketch of the world * B term sum
+            if plan.size % 2 == 0:
+                nat.call("ttsk_sum_slices", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr), B,
+                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 0, 2 * slot)
+            else:
+                for b in range(B):
+                    nat.call("ttsk_axpby", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr + 8 * b * stride),
+                             1.0, 1.0 if b else 0.0, ctypes.c_size_t(plan.size), 2 * slot)
+            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(sums[slot].ptr), ctypes.c_size_t(plan.size), 2 * slot)
 
     for _ in range(inflight):
         step_eager()
@@ -290,7 +301,7 @@ def main():
                     ld, rd = orc.TTDrm(lcores, shape, False), orc.TTDrm(rcores, shape, True)
                     rP, rO = orc.general_sketch("tt", all_cores[-1], ld, rd, "streaming")
                     want = np.concatenate([a.ravel() for a in rP + rO])
-                    got = out.get()[(B - 1) * plan.size:B * plan.size]
+                    got = out.get()[(B - 1) * stride:(B - 1) * stride + plan.size]
                     parity = max(parity, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
         ms_step = 1e3 * elapsed / args.steps
         result = dict(metric="TT-cores sketched/sec (fp64), stream_sketch d=6 n=200 r=50",
@@ -300,7 +311,8 @@ def main():
                       config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / "
                                            "right rank 100, streaming sketch (both chains, Omega, Psi), "
                                            f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight" +
-                                           ("; partial sketches summed by one RCCL all-reduce" if world > 1 else ""),
+                                           ("; the rank's partial sketches are summed and ONE RCCL all-reduce of one sketch per step "
+                                            "gives every rank the sketch of the whole sum" if world > 1 else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
                                   tts_per_step=B, steps_in_flight=inflight, single_sketch_latency_ms=single_ms,

@@ -85,6 +85,9 @@ int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *s
 /* y[i] = a*x[i] + b*y[i] on contiguous buffers: SketchContainer.__add__
  * (sketch_container.py:61-69) and the TensorSum accumulators (sketch_dispatch.py:93-136) */
 int ttsk_axpby(double *y, const double *x, double a, double b, size_t n, int stream);
+/* dst[i] (+)= sum_{b<nb} src[b*stride + i], i < n: the partial sketches of a batch summed into one
+ * (the `+=` loop of sum_sketch, sketch_dispatch.py:141-147); n, stride even, 16-byte aligned bases */
+int ttsk_sum_slices(double *dst, const double *src, int nb, size_t stride, size_t n, int accumulate, int stream);
 
 /* ---- TT input x TT DRMs: the whole streaming sketch in one call ---------------
  * general_sketch(TensorTrain, TensorTrainDRM, TensorTrainDRM, streaming)

@@ -384,6 +384,26 @@ def test_one_call_tt_path_matches_generic_and_oracle(tsa):
             assert rel(a.get(), c) < TOL and rel(b.get(), c) < TOL
 
 
+def test_sum_slices(tsa):
+    """ttsk_sum_slices == the `+=` loop over partial sketches (sketch_dispatch.py:141-147)."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(5)
+    nb, n, stride = 5, 10000, 10006
+    src = rng.standard_normal(nb * stride)
+    dst0 = rng.standard_normal(n)
+    want = sum(src[b * stride:b * stride + n] for b in range(nb))
+    for acc in (0, 1):
+        d, s_ = DevArray.from_host(dst0), DevArray.from_host(src)
+        nat.call("ttsk_sum_slices", ctypes.c_void_p(d.ptr), ctypes.c_void_p(s_.ptr), nb, ctypes.c_size_t(stride),
+                 ctypes.c_size_t(n), acc, 0)
+        assert rel(d.get(), want + acc * dst0) < 1e-15
+    with pytest.raises(ValueError):
+        nat.call("ttsk_sum_slices", ctypes.c_void_p(d.ptr), ctypes.c_void_p(s_.ptr), nb, ctypes.c_size_t(stride),
+                 ctypes.c_size_t(n - 1), 0, 0)
+
+
 def test_batched_one_call_path(tsa):
     """ttsk_tt_sketch_batch: nb tensors of one signature in one pass give, tensor by tensor, the
     sketch of the single-tensor call and of the oracle (rank slices included; nb > 8 is sliced)."""

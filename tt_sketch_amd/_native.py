@@ -56,6 +56,7 @@ def _bind(lib):
         "ttsk_gemm": [POINTER(GemmDesc), P, P, P, P, I],
         "ttsk_copy_strided": [P, P, I, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), I],
         "ttsk_axpby": [P, P, c_double, c_double, S, I],
+        "ttsk_sum_slices": [P, P, I, S, S, I, I],
         "ttsk_tt_sketch": [I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
         "ttsk_tt_sketch_batch": [I, I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, c_int64, I, I],
         "ttsk_prof_enable": [I],

@@ -101,6 +101,21 @@ __global__ void axpby_kernel(double *y, const double *x, double a, double b, siz
         y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
 
+// dst[i] (+)= sum_b src[b * stride + i]: the sketches of a batch summed into one (TensorSum)
+__global__ __launch_bounds__(256) void sum_slices_kernel(double2 *dst, const double2 *src, int nb, size_t stride2,
+                                                         size_t n2, int accumulate)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 acc = accumulate ? dst[i] : make_double2(0.0, 0.0);
+        for (int b = 0; b < nb; ++b) {
+            const double2 v = src[(size_t)b * stride2 + i];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        dst[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void mfma_probe_kernel(double *sink, int iters, double seed)
 {
     v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
@@ -304,6 +319,21 @@ int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *s
     int64_t blocks = cdiv(c.total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, c);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_sum_slices(double *dst, const double *src, int nb, size_t stride, size_t n, int accumulate, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dst && src && nb >= 1, "ttsk_sum_slices: bad argument");
+    TTSK_ARG(!(n & 1) && !(stride & 1) && !(((uintptr_t)dst | (uintptr_t)src) & 15),
+             "ttsk_sum_slices: length, stride and bases must be even / 16-byte aligned");
+    if (n == 0) return TTSK_OK;
+    size_t blocks = (n / 2 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (double2 *)dst, (const double2 *)src,
+                       nb, stride / 2, n / 2, accumulate);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

@@ -135,8 +135,13 @@ def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[lis
                 ptrs, k = plan.core_pointers(tt)
                 keep.append(k)
                 flat += [ptrs[i] for i in range(plan.d)]
-            tmp = DevArray.empty((len(chunk) * plan.size,))
-            plan.run_batch((ctypes.c_void_p * len(flat))(*flat), len(chunk), tmp, plan.size)
-            for b in range(len(chunk)):
-                axpby(out, tmp[b * plan.size:(b + 1) * plan.size], 1.0, 1.0)
+            stride = plan.size + (plan.size & 1)
+            tmp = DevArray.empty((len(chunk) * stride,))
+            plan.run_batch((ctypes.c_void_p * len(flat))(*flat), len(chunk), tmp, stride)
+            if plan.size % 2 == 0:
+                nat.call("ttsk_sum_slices", ctypes.c_void_p(out.ptr), ctypes.c_void_p(tmp.ptr), len(chunk),
+                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 1, 0)
+            else:
+                for b in range(len(chunk)):
+                    axpby(out, tmp[b * stride:b * stride + plan.size], 1.0, 1.0)
     return plan0.views(out)
