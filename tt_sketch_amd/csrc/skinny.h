@@ -20,6 +20,10 @@ namespace ttsk {
 
 constexpr int SK_MAXB = 8;   // problems of one shape per launch (one tensor of a batch each)
 
+#ifndef TTSK_S_M16
+#define TTSK_S_M16 1
+#endif
+
 struct SkinnyS {
     const double *W[SK_MAXB], *S[SK_MAXB];
     double *C[SK_MAXB];
@@ -162,7 +166,7 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     const double *wl_lane = Wl + kq * LDW + x16 + 16 * tile0;
     const int soffS = 16 * (sh_on ? tshared : 0) - 16 * tile0;
 
-    double accA[NTC][4], accB[4];
+    v4d accA[NTC], accB;      // [t]: the four 4x4x4 accumulators of a tile, or the 4 result registers of 16x16x4
 #pragma unroll
     for (int p = 0; p < NTC; ++p)
 #pragma unroll
@@ -172,10 +176,13 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
 
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(uniform_ptr(a.C[prob]), a.c_extent * 8);
     // acc[t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is D[4 beta + i][4((beta+t)&3) + j4]
-    const int e_m = 4 * ((lane >> 2) & 3) + (lane >> 4);
-    int e_j[4];
+    // (16x16x4 form: register t of lane l is D[4 t + (l >> 4)][l & 15])
+    int e_m[4], e_j[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) e_j[t] = 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+    for (int t = 0; t < 4; ++t) {
+        e_m[t] = TTSK_S_M16 ? 4 * t + (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
+        e_j[t] = TTSK_S_M16 ? (lane & 15) : 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+    }
     const uint32_t tile_step = (uint32_t)(16 * a.c_m * 8);
 
     while (g < a.groups) {
@@ -201,21 +208,28 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
                 for (int p = 0; p < NT; ++p) af[p] = wk[16 * p];
                 if (SH) as = wk[soffS];
                 double rA[4], rB[4];
+                const double sA = NT ? ringA[d] : 0.0, sB = SH ? ringB[d] : 0.0;
                 if (NT) {
-                    rot4(ringA[d], rA);
+                    if (!TTSK_S_M16) rot4(ringA[d], rA);
                     ringA[d] = fetch(nA, nkb_n, itn * D + d);
                 }
                 if (SH) {
-                    rot4(ringB[d], rB);
+                    if (!TTSK_S_M16) rot4(ringB[d], rB);
                     ringB[d] = fetch(nB, sh_on ? nkb_n : 0, itn * D + d);
                 }
+                if (TTSK_S_M16) {
 #pragma unroll
-                for (int p = 0; p < NT; ++p)
+                    for (int p = 0; p < NT; ++p) accA[p] = mfma16(af[p], sA, accA[p]);
+                    if (SH) accB = mfma16(as, sB, accB);
+                } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) accA[p][t] = mfma4(af[p], rA[t], accA[p][t]);
-                if (SH) {
+                    for (int p = 0; p < NT; ++p)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) accB[t] = mfma4(as, rB[t], accB[t]);
+                        for (int t = 0; t < 4; ++t) accA[p][t] = mfma4(af[p], rA[t], accA[p][t]);
+                    if (SH) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accB[t] = mfma4(as, rB[t], accB[t]);
+                    }
                 }
             }
         }
@@ -228,14 +242,14 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
                 int64_t dummy;
                 const int64_t ja = row_of((int64_t)g * RB + v, e_j[t], dummy);
                 const int64_t jb = row_of((int64_t)g * RB + 4, e_j[t], dummy);
-                const uint32_t oa = (uint32_t)((ja * a.c_j + (int64_t)e_m * a.c_m) * 8);
-                const uint32_t ob = (uint32_t)((jb * a.c_j + (int64_t)e_m * a.c_m) * 8);
+                const uint32_t oa = (uint32_t)((ja * a.c_j + (int64_t)e_m[t] * a.c_m) * 8);
+                const uint32_t ob = (uint32_t)((jb * a.c_j + (int64_t)e_m[t] * a.c_m) * 8);
 #pragma unroll
                 for (int p = 0; p < NT; ++p) {
-                    offs[p][t] = (ja >= 0 && 16 * (tile0 + p) + e_m < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
+                    offs[p][t] = (ja >= 0 && 16 * (tile0 + p) + e_m[t] < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
                     accA[p][t] *= a.alpha;
                 }
-                offt[t] = (sh_on && jb >= 0 && 16 * tshared + e_m < a.P) ? ob + tshared * tile_step : OOB_OFF;
+                offt[t] = (sh_on && jb >= 0 && 16 * tshared + e_m[t] < a.P) ? ob + tshared * tile_step : OOB_OFF;
                 accB[t] *= a.alpha;
             }
             if (a.accumulate) {
@@ -320,6 +334,13 @@ __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 // memory), so tiles are fetched in pairs: one 16-byte load per lane brings rows 2x and 2x+1 of a
 // 32-row block, i.e. the fragments of the "even rows" and the "odd rows" tile at once, 256
 // contiguous bytes per kappa.  Partial outputs go to slab[chunk][m][n]; skinny_r_reduce sums them.
+#ifndef TTSK_R_M16
+#define TTSK_R_M16 1
+#endif
+#ifndef TTSK_R_DEPTH
+#define TTSK_R_DEPTH 4     // kappa-blocks in flight per wave (8 measured no faster, 230 VGPRs)
+#endif
+
 struct SkinnyR {
     const double *A[SK_MAXB], *B[SK_MAXB];
     double *slab;       // [problem][chunk][m][n]
@@ -401,7 +422,7 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d);
 
-    double acc[TM][TN][4];
+    v4d acc[TM][TN];
 #pragma unroll
     for (int p = 0; p < TM; ++p)
 #pragma unroll
@@ -411,18 +432,26 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
 
     SK_STAMP(1);
     auto kblock = [&](int d, bool more) {
-        double af[TM], rB[TN][4];
+        double af[TM], bf[TN], rB[TN][4];
 #pragma unroll
         for (int p = 0; p < TM; ++p) af[p] = ringA[d][p];
 #pragma unroll
-        for (int q = 0; q < TN; ++q) rot4(ringB[d][q], rB[q]);
+        for (int q = 0; q < TN; ++q) {
+            bf[q] = ringB[d][q];
+            if (!TTSK_R_M16) rot4(ringB[d][q], rB[q]);
+        }
         if (more) issue(d);
 #pragma unroll
         for (int p = 0; p < TM; ++p)
 #pragma unroll
-            for (int q = 0; q < TN; ++q)
+            for (int q = 0; q < TN; ++q) {
+                if (TTSK_R_M16) {
+                    acc[p][q] = mfma16(af[p], bf[q], acc[p][q]);
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[p][q][t] = mfma4(af[p], rB[q][t], acc[p][q][t]);
+                    for (int t = 0; t < 4; ++t) acc[p][q][t] = mfma4(af[p], rB[q][t], acc[p][q][t]);
+                }
+            }
     };
     const int FULLIT = KB / D, TAIL = KB - FULLIT * D;
     for (int it = 0; it < FULLIT; ++it) {
@@ -435,16 +464,17 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     SK_STAMP(3);
     // acc[p][q][t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is fragment element
     // (r = 4 beta + i, c = 4((beta+t)&3) + j4); pair fragments 2p / 2p+1 are rows 32p + 2r + {0,1}
+    // (16x16x4 form: register t of lane l is fragment element (r = 4 t + (l >> 4), c = l & 15))
     double *slab = a.slab + (int64_t)blockIdx.x * a.M * a.N;
-    const int r16 = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
     for (int p = 0; p < TM; ++p) {
-        const int m = p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16;
-        if (m < a.M) {
-            double *srow = slab + (int64_t)m * a.N;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int c16 = 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+        for (int t = 0; t < 4; ++t) {
+            const int r16 = TTSK_R_M16 ? 4 * t + (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
+            const int c16 = TTSK_R_M16 ? (lane & 15) : 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
+            const int m = p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16;
+            if (m < a.M) {
+                double *srow = slab + (int64_t)m * a.N;
 #pragma unroll
                 for (int q = 0; q < PB; ++q) {
                     const int n = col0 + 32 * q + 2 * c16;     // even N (16-byte loads) => n + 1 < N too

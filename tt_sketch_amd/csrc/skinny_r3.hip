@@ -6,7 +6,7 @@ namespace ttsk {
 template <int NMT, int NNT>
 static int launch_r_one(const SkinnyR &a, int grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((skinny_r_kernel<NMT, NNT, 4>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((skinny_r_kernel<NMT, NNT, TTSK_R_DEPTH>), dim3((unsigned)grid), dim3(512), 0, st, a);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
