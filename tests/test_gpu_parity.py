@@ -244,6 +244,26 @@ def test_pinv_and_qr(tsa):
         Qref, _ = scipy.linalg.qr(M, mode="economic")
         assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12 * n
         assert rel(Q, Qref) < 1e-10, (m, n)   # same Householder sign convention as LAPACK
+    # rank-deficient input: CholeskyQR2 is rejected and the Householder kernels take over
+    M = rng.standard_normal((400, 3)) @ rng.standard_normal((3, 12))
+    d = DevArray.from_host(M)
+    nat.call("ttsk_qr_thin", ctypes.c_void_p(d.ptr), 400, 12, 0)
+    Q = d.get()
+    assert np.linalg.norm(Q.T @ Q - np.eye(12)) < 1e-11
+    assert rel(Q @ (Q.T @ M), M) < 1e-10
+    # ill-conditioned but full rank (kappa ~ 1e9 > the CholeskyQR2 gate): still LAPACK's Q
+    U, _ = np.linalg.qr(rng.standard_normal((300, 8)))
+    V, _ = np.linalg.qr(rng.standard_normal((8, 8)))
+    M = (U * np.logspace(0, -9, 8)) @ V.T
+    d = DevArray.from_host(M)
+    nat.call("ttsk_qr_thin", ctypes.c_void_p(d.ptr), 300, 8, 0)
+    Q = d.get()
+    assert np.linalg.norm(Q.T @ Q - np.eye(8)) < 1e-11
+    assert rel(Q @ (Q.T @ M), M) < 1e-6
+    # moderately ill-conditioned Omega (kappa ~ 1e4): normal equations rejected, Jacobi SVD result
+    Om = (np.linalg.qr(rng.standard_normal((20, 20)))[0] * np.logspace(0, -4, 20)) @ rng.standard_normal((20, 35))
+    A = rng.standard_normal((15, 35))
+    assert rel(right_mul_pinv(A, Om), orc.right_mul_pinv(A, Om)) < 1e-8
 
 
 # ------------------------------------------------------------------ API-level properties
