@@ -99,6 +99,11 @@ def test_chain_kernels_against_einsum(tsa):
     out = DevArray.from_host(np.full((6000, 100), 2.0))
     contract("mk,kc->mc", DevArray.from_host(T), Rd, out=out, accumulate=True, alpha=-0.5)
     assert rel(out.get(), 2.0 - 0.5 * T @ R[:, 10:110]) < 1e-13
+    # long-K with a genuinely two-level contraction index (k is a slice of a longer axis, so the
+    # (q, k) walk wraps at every q) and chunk boundaries that fall inside a q
+    Tbig, Ebig = rng.standard_normal((9, 700, 34)), rng.standard_normal((9, 650, 50))
+    got = contract("qkp,qkm->pm", DevArray.from_host(Tbig)[:, 3:603, :], DevArray.from_host(Ebig)[:, 10:610, :]).get()
+    assert rel(got, np.einsum("qkp,qkm->pm", Tbig[:, 3:603, :], Ebig[:, 10:610, :])) < 1e-13
     # long-K with accumulate / alpha applied by the slab reduction
     A, B = rng.standard_normal((8192, 60)), rng.standard_normal((8192, 40))
     out = DevArray.from_host(np.ones((60, 40)))
@@ -402,6 +407,36 @@ def test_one_call_tt_path_matches_generic_and_oracle(tsa):
         oP, oO = orc.general_sketch(data[0], data[1], ld, rd, "streaming")
         for a, b, c in zip(fused[0] + fused[1], gen[0] + gen[1], oP + oO):
             assert rel(a.get(), c) < TOL and rel(b.get(), c) < TOL
+
+
+def test_rccl_single_rank(tsa):
+    """The RCCL path of the partial-sketch sum with a communicator of one rank: all-reduce and
+    reduce leave the buffer unchanged and the calls succeed on a library stream.  Runs in a child
+    process under a time limit (communicator set-up loads RCCL's kernels, ~6 s, and must not be
+    able to stall the suite)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, numpy as np\n"
+        "from tt_sketch_amd import _native as nat\n"
+        "from tt_sketch_amd.device import DevArray, sync\n"
+        "from tt_sketch_amd.distributed import RcclComm\n"
+        "nat.call('ttsk_init', 0)\n"
+        "x = np.random.default_rng(9).standard_normal(100003)\n"
+        "buf = DevArray.from_host(x)\n"
+        "comm = RcclComm(0, 1, lambda b: b)\n"
+        "comm.allreduce_sum(buf, stream=2)\n"
+        "comm.reduce_sum(buf, root=0, stream=2)\n"
+        "sync()\n"
+        "assert np.array_equal(buf.get(), x)\n"
+        "comm.close()\n"
+        "print('rccl single rank ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL communicator set-up did not return within 150 s on this box")
+    assert res.returncode == 0 and "rccl single rank ok" in res.stdout, res.stderr[-2000:]
 
 
 def test_sum_slices(tsa):
