@@ -468,6 +468,10 @@ def test_batched_one_call_path(tsa):
     rng = np.random.default_rng(23)
     for shape, ranks, lr, rr, nb in [((9, 12, 7, 10, 8), (3, 6, 5, 4), (4, 7, 6, 5), (6, 9, 8, 7), 3),
                                      ((64, 48, 64), (40, 36), (20, 24), (30, 28), 2),
+                                     # large enough for the chain kernels: even ranks (long-K kernel) and odd
+                                     # ranks (streamed kernel with tails, generic split-K for GEMM2)
+                                     ((150, 160, 150, 140), (30, 32, 28), (26, 24, 22), (28, 30, 34), 3),
+                                     ((150, 151, 149), (31, 29), (25, 27), (33, 35), 2),
                                      ((5, 4, 6), (3, 2), (2, 3), (4, 3), 11)]:
         ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
         if len(shape) == 5:
