@@ -38,6 +38,7 @@ struct SkinnyS {
     int64_t s_u;
     int U, V, nbv, tvl;
     int64_t c_m, c_j;   // C[m][j]
+    int64_t c_u;        // two-level streamed index: C[m][u][v] at m c_m + u c_u + v c_j
     int64_t J;
     int P, K, groups;
     int64_t s_extent, w_extent, c_extent;   // elements addressable from each base (all < 2^29)
@@ -126,17 +127,17 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     const int nkb_lane = (a.K - kq + 3) >> 2;          // k-blocks in which this lane's k = 4 kb + kq is < K
     const bool sh_on = SH && tshared < NPT;
 
-    // streamed row c16 of row block rb: its index j (also the output column), or -1 past the end
+    // streamed row c16 of row block rb: the element offset of its output column, or -1 past the end
     auto row_of = [&](int64_t rb, int c16, int64_t &in_off) -> int64_t {
         if (a.U == 1) {
             const int64_t j = rb * 16 + c16;
             in_off = j * a.s_j;
-            return j < a.J ? j : -1;
+            return j < a.J ? j * a.c_j : -1;
         }
         const int bu = (int)((uint32_t)rb / (uint32_t)a.nbv), bv = (int)rb - bu * a.nbv;
         const int u = (bu << (4 - a.tvl)) + (c16 >> a.tvl), vv = (bv << a.tvl) + (c16 & ((1 << a.tvl) - 1));
         in_off = (int64_t)u * a.s_u + (int64_t)vv * a.s_j;
-        return (u < a.U && vv < a.V) ? (int64_t)u * a.V + vv : -1;
+        return (u < a.U && vv < a.V) ? (int64_t)u * a.c_u + (int64_t)vv * a.c_j : -1;
     };
     auto lane_off = [&](int64_t rb) -> uint32_t {
         int64_t in_off;
@@ -242,8 +243,8 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
                 int64_t dummy;
                 const int64_t ja = row_of((int64_t)g * RB + v, e_j[t], dummy);
                 const int64_t jb = row_of((int64_t)g * RB + 4, e_j[t], dummy);
-                const uint32_t oa = (uint32_t)((ja * a.c_j + (int64_t)e_m[t] * a.c_m) * 8);
-                const uint32_t ob = (uint32_t)((jb * a.c_j + (int64_t)e_m[t] * a.c_m) * 8);
+                const uint32_t oa = (uint32_t)((ja + (int64_t)e_m[t] * a.c_m) * 8);
+                const uint32_t ob = (uint32_t)((jb + (int64_t)e_m[t] * a.c_m) * 8);
 #pragma unroll
                 for (int p = 0; p < NT; ++p) {
                     offs[p][t] = (ja >= 0 && 16 * (tile0 + p) + e_m[t] < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;

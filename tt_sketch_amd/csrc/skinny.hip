@@ -187,9 +187,9 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     // which side streams?  A batch index joins the streamed index when the small operand is shared
     // by the batch and the output is contiguous across it (right chain GEMM1: b = k, n = p'').
     const bool a_small = d.M <= 128 && d.batch * d.N >= 2048 && d.M <= d.N &&
-                         (d.batch == 1 || (d.a_b == 0 && d.c_b == d.N * d.c_n));
+                         (d.batch == 1 || (d.a_b == 0 && d.c_b >= 0));
     const bool b_small = !a_small && d.N <= 128 && d.batch * d.M >= 2048 &&
-                         (d.batch == 1 || (d.b_b == 0 && d.c_b == d.M * d.c_m));
+                         (d.batch == 1 || (d.b_b == 0 && d.c_b >= 0));
     if (!a_small && !b_small) return 0;
     SkinnyS s{};
     s.nb = nb;
@@ -220,10 +220,11 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     { const char *e = getenv("TTSK_SK_STAMPS"); s.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     s.s_extent = (d.batch - 1) * s.s_u + ((int64_t)s.V - 1) * s.s_j + (K - 1) * s.s_k + 1;
     s.w_extent = (K - 1) * s.w_k + (s.P - 1) * s.w_m + 1;
-    s.c_extent = (s.P - 1) * s.c_m + (s.J - 1) * s.c_j + 1;
+    s.c_u = d.batch == 1 ? 0 : d.c_b;
+    s.c_extent = (s.P - 1) * s.c_m + (d.batch - 1) * s.c_u + ((int64_t)(d.batch == 1 ? s.J : s.V) - 1) * s.c_j + 1;
     // 32-bit byte offsets, including the rows of the last (partial) group and the padded k-blocks
     const int64_t reach = ((d.batch + 4) * s.s_u + ((int64_t)s.V + 96) * s.s_j + (K + 24) * s.s_k) * 8;
-    const int64_t reach_c = ((s.J + 96) * s.c_j + 144 * s.c_m) * 8;
+    const int64_t reach_c = ((d.batch + 4) * s.c_u + ((int64_t)(d.batch == 1 ? s.J : s.V) + 96) * s.c_j + 144 * s.c_m) * 8;
     if (reach >= (1ll << 32) - 64 || reach_c >= (1ll << 32) - 64 || s.w_extent * 8 >= (1ll << 31)) return 0;
     const int npt = (int)cdiv(s.P, 16);
     if ((size_t)((cdiv(K, 4) + 4) * 4 * ldmf(16 * npt) + 16) * 8 + 2048 > 160 * 1024) return 0;
