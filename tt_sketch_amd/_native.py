@@ -118,5 +118,17 @@ def check(rc):
     raise TtskError(msg)
 
 
+_sync_epoch = 0
+
+
+def sync_epoch() -> int:
+    """Number of device-wide synchronisations so far (device.py recycles a large buffer only after
+    one has happened since its release)."""
+    return _sync_epoch
+
+
 def call(name, *args):
+    global _sync_epoch
     check(getattr(lib(), name)(*args))
+    if name == "ttsk_sync" and args and int(args[0]) < 0:
+        _sync_epoch += 1

@@ -23,20 +23,70 @@ from . import _native as nat
 _F64 = np.dtype(np.float64)
 
 
+# Large allocations are recycled: hipMalloc / hipFree of GB-sized buffers cost 10-100 ms each (the
+# dense-tensor path allocates several per sketch and was swinging between 80 and 500 ms per call).
+# hipFree waits for the device; a recycled buffer gets the same guarantee by being handed out again
+# only after a device-wide ttsk_sync has happened since its release (nat.sync_epoch()).
+_POOL_MIN = 8 << 20          # bytes; smaller buffers go straight to ttsk_malloc / ttsk_free
+_POOL_CAP = 48 << 30         # bytes kept at most
+_pool: "dict[int, list]" = {}   # rounded size -> [(release_epoch, ptr), ...]
+_pool_bytes = 0
+
+
+def _pool_round(nbytes: int) -> int:
+    return (int(nbytes) + (2 << 20) - 1) & ~((2 << 20) - 1)
+
+
+def _pool_take(size: int):
+    global _pool_bytes
+    lst = _pool.get(size)
+    if lst:
+        epoch = nat.sync_epoch()
+        for i, (rel, ptr) in enumerate(lst):
+            if rel < epoch:
+                del lst[i]
+                _pool_bytes -= size
+                return ptr
+    return None
+
+
+def _pool_give(size: int, ptr: int) -> None:
+    global _pool_bytes
+    _pool.setdefault(size, []).append((nat.sync_epoch(), ptr))
+    _pool_bytes += size
+    while _pool_bytes > _POOL_CAP:          # drop the largest class first
+        big = max((k for k, v in _pool.items() if v), default=None)
+        if big is None:
+            break
+        _, old = _pool[big].pop(0)
+        _pool_bytes -= big
+        nat.lib().ttsk_free(ctypes.c_void_p(old))
+
+
 class _Buffer:
-    """Owns one ttsk_malloc allocation."""
-    __slots__ = ("ptr", "nbytes")
+    """Owns one ttsk_malloc allocation (recycled through the pool above when large)."""
+    __slots__ = ("ptr", "nbytes", "_pooled")
 
     def __init__(self, nbytes: int):
-        p = ctypes.c_void_p()
-        nat.call("ttsk_malloc", ctypes.byref(p), ctypes.c_size_t(max(int(nbytes), 8)))
-        self.ptr = p.value
         self.nbytes = int(nbytes)
+        self._pooled = 0
+        if self.nbytes >= _POOL_MIN:
+            self._pooled = _pool_round(self.nbytes)
+            got = _pool_take(self._pooled)
+            if got is not None:
+                self.ptr = got
+                return
+        p = ctypes.c_void_p()
+        nat.call("ttsk_malloc", ctypes.byref(p), ctypes.c_size_t(max(self._pooled or self.nbytes, 8)))
+        self.ptr = p.value
 
     def __del__(self):
         try:
             if self.ptr:
-                nat.lib().ttsk_free(ctypes.c_void_p(self.ptr))
+                if self._pooled:
+                    _pool_give(self._pooled, self.ptr)
+                else:
+                    nat.lib().ttsk_free(ctypes.c_void_p(self.ptr))
         except Exception:  # interpreter shutdown
             pass
         self.ptr = None
