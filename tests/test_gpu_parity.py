@@ -87,6 +87,9 @@ def test_chain_kernels_against_einsum(tsa):
         ("kp,kq->pq", (4100, 2), (4100, 128)), ("kp,kq->pq", (9999, 34), (9999, 66)),
         ("qkp,qkm->pm", (7, 601, 18), (7, 601, 122)), ("qkp,qkm->pm", (300, 14, 100), (300, 14, 30)),
         ("kp,kq->pq", (5000, 128), (5000, 128)), ("kp,kq->pq", (4097, 16), (4097, 16)),
+        # long-K with the longer side cut into row tiles of 128 (dense unfoldings: 20 x K times K x 4096)
+        ("kp,kq->pq", (6000, 300), (6000, 20)), ("kp,kq->pq", (4100, 18), (4100, 1000)),
+        ("kp,kq->pq", (70000, 130), (70000, 64)), ("kp,kq->pq", (4096, 2), (4096, 4098)),
     ]
     for spec, sa, sb in specs:
         A, B = rng.standard_normal(sa), rng.standard_normal(sb)

@@ -185,6 +185,12 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
     TTSK_ARG(d.batch >= 0 && d.M >= 0 && d.N >= 0 && d.Ko >= 0 && d.Ki >= 0, "ttsk_gemm: negative size");
     if (d.batch == 0 || d.M == 0 || d.N == 0) return TTSK_OK;
     const int64_t K = d.Ko * d.Ki;
+    static int trace = [] { const char *e = getenv("TTSK_GEMM_TRACE"); return e ? atoi(e) : 0; }();
+    if (trace)
+        fprintf(stderr, "ttsk_gemm b=%lld M=%lld N=%lld Ko=%lld Ki=%lld | a: b%lld m%lld ko%lld ki%lld | b: b%lld ko%lld ki%lld n%lld | c: b%lld m%lld n%lld acc=%d\n",
+                (long long)d.batch, (long long)d.M, (long long)d.N, (long long)d.Ko, (long long)d.Ki, (long long)d.a_b,
+                (long long)d.a_m, (long long)d.a_ko, (long long)d.a_ki, (long long)d.b_b, (long long)d.b_ko,
+                (long long)d.b_ki, (long long)d.b_n, (long long)d.c_b, (long long)d.c_m, (long long)d.c_n, d.accumulate);
     if (K == 0) {
         if (!d.accumulate) {
             hipLaunchKernelGGL(fill3_kernel, dim3(256), dim3(256), 0, st, C, d.batch, d.M, d.N, d.c_b,

@@ -345,11 +345,16 @@ __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 struct SkinnyR {
     const double *A[SK_MAXB], *B[SK_MAXB];
     double *slab;       // [problem][chunk][m][n]
-    int nb, chunks;     // workgroup x serves chunk x % chunks of problem x / chunks
+    int nb, chunks;     // workgroup x serves chunk x % chunks of (problem, row tile) x / chunks
     int64_t a_ko, a_ki, b_ko, b_ki;
     int64_t Ki, K, chunk;
     int64_t a_extent, b_extent;
-    int M, N;
+    int M, N;           // rows of one row tile (<= 128), columns (<= 128)
+    // A's row dimension may be longer than 128: m_tiles tiles of M rows, Mtot rows in all (the dense
+    // unfoldings: 20 x K times K x 4096 ... ).  With a single-level kappa (`rebase`) every workgroup
+    // addresses its operands from its own chunk / tile origin, so operands beyond 4 GB are fine.
+    int m_tiles, rebase;
+    int64_t Mtot;
     long long *stamps;
 };
 
@@ -367,17 +372,23 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     const int lane = threadIdx.x & 63;
     const int x16 = lane & 15, kq = lane >> 4;
     SK_STAMP(0);
-    const int prob = blockIdx.x / a.chunks, ci = blockIdx.x - prob * a.chunks;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(uniform_ptr(a.A[prob]), a.a_extent * 8);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(uniform_ptr(a.B[prob]), a.b_extent * 8);
+    const int pt = blockIdx.x / a.chunks, ci = blockIdx.x - pt * a.chunks;
+    const int prob = pt / a.m_tiles, mtile = pt - prob * a.m_tiles;
     const int64_t k0 = (int64_t)ci * a.chunk;
     const int64_t len = a.K - k0 < a.chunk ? a.K - k0 : a.chunk;
     const int nkb_lane = (int)((len - kq + 3) >> 2);
     const int KB = (int)((len + 3) >> 2);
+    const int64_t tile_row0 = (int64_t)mtile * a.M;                 // first row of this tile in A
+    const int rows_here = (int)(a.Mtot - tile_row0 < a.M ? a.Mtot - tile_row0 : a.M);
+    // operand origins of this workgroup (rebase: + the chunk's kappa offset; every out-of-range lane is
+    // masked explicitly, the descriptor's own range check is then only the OOB_OFF sentinel)
+    const int64_t a_org = tile_row0 + (a.rebase ? k0 * a.a_ki : 0), b_org = a.rebase ? k0 * a.b_ki : 0;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(uniform_ptr(a.A[prob]) + a_org, a.rebase ? (int64_t)OOB_OFF : (a.a_extent - tile_row0) * 8);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(uniform_ptr(a.B[prob]) + b_org, a.rebase ? (int64_t)OOB_OFF : a.b_extent * 8);
 
     // per-lane walk over kappa = k0 + kq + 4 i: byte offsets of A's and B's kappa part
-    const int64_t kap = k0 + kq;
-    const int64_t ko0 = a.Ki == a.K ? 0 : kap / a.Ki;
+    const int64_t kap = (a.rebase ? 0 : k0) + kq;
+    const int64_t ko0 = (a.rebase || a.Ki == a.K) ? 0 : kap / a.Ki;
     int ki = (int)(kap - ko0 * a.Ki);
     uint32_t offA = (uint32_t)((ko0 * a.a_ko + (int64_t)ki * a.a_ki) * 8);
     uint32_t offB = (uint32_t)((ko0 * a.b_ko + (int64_t)ki * a.b_ki) * 8);
@@ -387,8 +398,8 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     // column (element) offsets inside a kappa row; elements past M / N are masked per lane
     uint32_t rowA[PA + SA], colB[PB + SB];
 #pragma unroll
-    for (int p = 0; p < PA; ++p) rowA[p] = row0 + 32 * p + 2 * x16 < a.M ? (uint32_t)(row0 + 32 * p + 2 * x16) * 8u : OOB_OFF;
-    if (SA) rowA[PA] = row0 + 32 * PA + x16 < a.M ? (uint32_t)(row0 + 32 * PA + x16) * 8u : OOB_OFF;
+    for (int p = 0; p < PA; ++p) rowA[p] = row0 + 32 * p + 2 * x16 < rows_here ? (uint32_t)(row0 + 32 * p + 2 * x16) * 8u : OOB_OFF;
+    if (SA) rowA[PA] = row0 + 32 * PA + x16 < rows_here ? (uint32_t)(row0 + 32 * PA + x16) * 8u : OOB_OFF;
 #pragma unroll
     for (int q = 0; q < PB; ++q) colB[q] = col0 + 32 * q + 2 * x16 < a.N ? (uint32_t)(col0 + 32 * q + 2 * x16) * 8u : OOB_OFF;
     if (SB) colB[PB] = col0 + 32 * PB + x16 < a.N ? (uint32_t)(col0 + 32 * PB + x16) * 8u : OOB_OFF;
@@ -474,7 +485,7 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
             const int r16 = TTSK_R_M16 ? 4 * t + (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
             const int c16 = TTSK_R_M16 ? (lane & 15) : 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
             const int m = p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16;
-            if (m < a.M) {
+            if (m < rows_here) {
                 double *srow = slab + (int64_t)m * a.N;
 #pragma unroll
                 for (int q = 0; q < PB; ++q) {
@@ -495,23 +506,49 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     }
 }
 
+// 8 waves over the (<= 8) x (<= 8) tiles of the output: 2 row halves x 4 column strips, or -- when
+// there are at most 4 column tiles -- 4 row quarters x 2 column strips, which keeps all waves busy
+// and needs 2 instead of 3 loads per 4 tiles on the narrow shapes (left chain: 7 x 4 tiles).
 template <int NMT, int NNT, int D>
 __global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
 {
-    constexpr int H0 = (NMT + 1) / 2, H1 = NMT / 2;          // tiles of the two row halves
-    constexpr int TN = (NNT + 3) / 4;                        // tiles per column strip (1 or 2)
-    constexpr int FULL = NNT / TN, REST = NNT - FULL * TN;   // FULL strips of TN tiles, then one of REST
     const int w = threadIdx.x >> 6, s = w & 3, h = w >> 2;
-    if (h == 0) {
-        if (s < FULL) skinny_r_wave<H0 / 2, H0 % 2, TN / 2, TN % 2, D>(a, 0, 16 * s * TN);
-        if constexpr (REST > 0) {
-            if (s == FULL) skinny_r_wave<H0 / 2, H0 % 2, REST / 2, REST % 2, D>(a, 0, 16 * s * TN);
+    if constexpr (NNT <= 4) {
+        constexpr int TQ = (NMT + 3) / 4;                    // row tiles per quarter (1 or 2)
+        constexpr int TS = (NNT + 1) / 2;                    // column tiles per strip (1 or 2)
+        const int rows = NMT - s * TQ < TQ ? NMT - s * TQ : TQ;          // <= 0: nothing for this wave
+        const int cols = NNT - h * TS < TS ? NNT - h * TS : TS;
+        if (rows <= 0 || cols <= 0) return;
+        const int row0 = 16 * s * TQ, col0 = 16 * h * TS;
+        if constexpr (TQ == 2 && TS == 2) {
+            if (rows == 2 && cols == 2) skinny_r_wave<1, 0, 1, 0, D>(a, row0, col0);
+            else if (rows == 2) skinny_r_wave<1, 0, 0, 1, D>(a, row0, col0);
+            else if (cols == 2) skinny_r_wave<0, 1, 1, 0, D>(a, row0, col0);
+            else skinny_r_wave<0, 1, 0, 1, D>(a, row0, col0);
+        } else if constexpr (TQ == 2) {
+            if (rows == 2) skinny_r_wave<1, 0, 0, 1, D>(a, row0, col0);
+            else skinny_r_wave<0, 1, 0, 1, D>(a, row0, col0);
+        } else if constexpr (TS == 2) {
+            if (cols == 2) skinny_r_wave<0, 1, 1, 0, D>(a, row0, col0);
+            else skinny_r_wave<0, 1, 0, 1, D>(a, row0, col0);
+        } else {
+            skinny_r_wave<0, 1, 0, 1, D>(a, row0, col0);
         }
     } else {
-        if constexpr (H1 > 0) {
-            if (s < FULL) skinny_r_wave<H1 / 2, H1 % 2, TN / 2, TN % 2, D>(a, 16 * H0, 16 * s * TN);
+        constexpr int H0 = (NMT + 1) / 2, H1 = NMT / 2;          // tiles of the two row halves
+        constexpr int TN = (NNT + 3) / 4;                        // tiles per column strip (2 here)
+        constexpr int FULL = NNT / TN, REST = NNT - FULL * TN;   // FULL strips of TN tiles, then one of REST
+        if (h == 0) {
+            if (s < FULL) skinny_r_wave<H0 / 2, H0 % 2, TN / 2, TN % 2, D>(a, 0, 16 * s * TN);
             if constexpr (REST > 0) {
-                if (s == FULL) skinny_r_wave<H1 / 2, H1 % 2, REST / 2, REST % 2, D>(a, 16 * H0, 16 * s * TN);
+                if (s == FULL) skinny_r_wave<H0 / 2, H0 % 2, REST / 2, REST % 2, D>(a, 0, 16 * s * TN);
+            }
+        } else {
+            if constexpr (H1 > 0) {
+                if (s < FULL) skinny_r_wave<H1 / 2, H1 % 2, TN / 2, TN % 2, D>(a, 16 * H0, 16 * s * TN);
+                if constexpr (REST > 0) {
+                    if (s == FULL) skinny_r_wave<H1 / 2, H1 % 2, REST / 2, REST % 2, D>(a, 16 * H0, 16 * s * TN);
+                }
             }
         }
     }

@@ -14,15 +14,16 @@ int launch_skinny_r_1(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t 
 int launch_skinny_r_2(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
 int launch_skinny_r_3(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
 
-// out[m, n] (+)= alpha sum_c slab[c][m][n]; 16 chunk lanes x 16 consecutive n per workgroup
 struct ReduceOut { double *C[SK_MAXB]; };
+// out[m, n] (+)= alpha sum_c slab[c][m][n] per (problem, row tile) y; 16 chunk lanes x 16 consecutive n
 __global__ __launch_bounds__(256) void skinny_r_reduce(const double *__restrict__ slab_all, int chunks, int M, int N,
-                                                       ReduceOut outs, int64_t c_m, int64_t c_n, double alpha,
-                                                       int accumulate)
+                                                       int m_tiles, int64_t Mtot, ReduceOut outs, int64_t c_m,
+                                                       int64_t c_n, double alpha, int accumulate)
 {
     __shared__ double part[16][17];
+    const int prob = blockIdx.y / m_tiles, tile = blockIdx.y - prob * m_tiles;
     const double *__restrict__ slab = slab_all + (int64_t)blockIdx.y * chunks * M * N;
-    double *__restrict__ C = outs.C[blockIdx.y];
+    double *__restrict__ C = outs.C[prob];
     const int x = threadIdx.x & 15, z = threadIdx.x >> 4;
     const int64_t e = (int64_t)blockIdx.x * 16 + x, MN = (int64_t)M * N;
     double sum = 0.0;
@@ -42,8 +43,11 @@ __global__ __launch_bounds__(256) void skinny_r_reduce(const double *__restrict_
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += part[k][x];
         const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
-        double *c = C + m * c_m + n * c_n;
-        *c = accumulate ? *c + alpha * tot : alpha * tot;
+        const int64_t row = (int64_t)tile * M + m;
+        if (row < Mtot) {
+            double *c = C + row * c_m + n * c_n;
+            *c = accumulate ? *c + alpha * tot : alpha * tot;
+        }
     }
 }
 
@@ -102,13 +106,14 @@ static int run_s(SkinnyS a, hipStream_t st, int *prof, double flops)
     return launch_skinny_s_depth<5>(a, npt, spt, lds, grid, st);
 }
 
-// long-K: both M, N <= 128, both operands contiguous along their non-contracted index, 16-byte
-// loads possible (even extents / strides, aligned bases); desc not collapsed (two-level kappa ok)
+// long-K: one side <= 128, the other <= 128 or cut into row tiles of 128; both operands contiguous
+// along their non-contracted index, 16-byte loads possible (even extents / strides, aligned bases);
+// desc not collapsed (two-level kappa ok when the operands stay below 4 GB)
 static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const double *const *B, double *const *C,
                  int stream, hipStream_t st)
 {
     const int64_t K = d.Ko * d.Ki;
-    if (d.M > 128 || d.N > 128 || K < 4096) return 0;
+    if ((d.M > 128 && d.N > 128) || K < 4096) return 0;
     if (d.Ko > 1 && d.Ki < 4) return 0;
     if (d.a_m != 1 || d.b_n != 1 || d.a_ko < 0 || d.a_ki < 0 || d.b_ko < 0 || d.b_ki < 0) return 0;
     if ((d.M | d.N | d.a_ko | d.a_ki | d.b_ko | d.b_ki) & 1) return 0;
@@ -116,15 +121,21 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
         if (((uintptr_t)A[b] | (uintptr_t)B[b]) & 15) return 0;
     SkinnyR r{};
     r.nb = nb;
-    // the operand with more 16-row tiles plays "A" (row halves), the other "B" (column strips)
+    // the operand with more 16-row tiles plays "A" (rows, tiled by 128 when longer), the other "B"
     const bool swap = cdiv(d.N, 16) > cdiv(d.M, 16);
+    int64_t big, small_;
     if (!swap) {
-        r.a_ko = d.a_ko; r.a_ki = d.a_ki; r.M = (int)d.M;
-        r.b_ko = d.b_ko; r.b_ki = d.b_ki; r.N = (int)d.N;
+        r.a_ko = d.a_ko; r.a_ki = d.a_ki; big = d.M;
+        r.b_ko = d.b_ko; r.b_ki = d.b_ki; small_ = d.N;
     } else {
-        r.a_ko = d.b_ko; r.a_ki = d.b_ki; r.M = (int)d.N;
-        r.b_ko = d.a_ko; r.b_ki = d.a_ki; r.N = (int)d.M;
+        r.a_ko = d.b_ko; r.a_ki = d.b_ki; big = d.N;
+        r.b_ko = d.a_ko; r.b_ki = d.a_ki; small_ = d.M;
     }
+    r.Mtot = big;
+    r.M = (int)(big < 128 ? big : 128);
+    r.m_tiles = (int)cdiv(big, 128);
+    r.N = (int)small_;
+    if ((int64_t)nb * r.m_tiles > 60000) return 0;
     for (int b = 0; b < nb; ++b) {
         r.A[b] = swap ? B[b] : A[b];
         r.B[b] = swap ? A[b] : B[b];
@@ -133,35 +144,53 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     r.Ki = d.Ki;
     r.K = K;
     if (d.Ko > 1 && r.a_ko == d.Ki * r.a_ki && r.b_ko == d.Ki * r.b_ki) r.Ki = K;   // uniform walk
+    r.rebase = r.Ki == K ? 1 : 0;
     { const char *e = getenv("TTSK_SK_STAMPS"); r.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
-    r.a_extent = (r.M - 1) + (d.Ko - 1) * r.a_ko + (d.Ki - 1) * r.a_ki + 1;
+    r.a_extent = (big - 1) + (d.Ko - 1) * r.a_ko + (d.Ki - 1) * r.a_ki + 1;
     r.b_extent = (r.N - 1) + (d.Ko - 1) * r.b_ko + (d.Ki - 1) * r.b_ki + 1;
-    // 32-bit byte offsets including the kappa walk past the end of the last chunk
-    const int64_t reach_a = (144 + (d.Ko + 1) * r.a_ko + (d.Ki + 64) * r.a_ki) * 8;
-    const int64_t reach_b = (144 + (d.Ko + 1) * r.b_ko + (d.Ki + 64) * r.b_ki) * 8;
-    if (reach_a >= (1ll << 32) - 64 || reach_b >= (1ll << 32) - 64) return 0;
     const int cus = num_cu() / nb > 0 ? num_cu() / nb : 1;
-    r.chunk = cdiv(cdiv(K, cus), 4) * 4;
+    const int64_t want_chunks = cus / r.m_tiles > 0 ? cus / r.m_tiles : 1;
+    r.chunk = cdiv(cdiv(K, want_chunks), 4) * 4;
+    if (r.chunk < 64) r.chunk = 64;
+    if (r.rebase) {
+        // per-workgroup origins: 32-bit offsets only have to span one chunk and one row tile; shorter
+        // chunks when a kappa row is so long (an unfolding with 2 MB rows) that a chunk would not fit
+        auto span = [&](int64_t chunk) {
+            const int64_t sa = (144 + (chunk + 64) * r.a_ki) * 8, sb = (144 + (chunk + 64) * r.b_ki) * 8;
+            return sa > sb ? sa : sb;
+        };
+        while (span(r.chunk) >= (1ll << 32) - 64 && r.chunk > 64) r.chunk = cdiv(r.chunk / 2, 4) * 4;
+        if (span(r.chunk) >= (1ll << 32) - 64) return 0;
+    }
     const int chunks = (int)cdiv(K, r.chunk);
     r.chunks = chunks;
+    if ((int64_t)nb * r.m_tiles * chunks > (1 << 30) / 8) return 0;
+    if (!r.rebase) {
+        // 32-bit byte offsets including the kappa walk past the end of the last chunk
+        const int64_t reach_a = (big + 144 + (d.Ko + 1) * r.a_ko + (d.Ki + 64) * r.a_ki) * 8;
+        const int64_t reach_b = (144 + (d.Ko + 1) * r.b_ko + (d.Ki + 64) * r.b_ki) * 8;
+        if (reach_a >= (1ll << 32) - 64 || reach_b >= (1ll << 32) - 64) return 0;
+    }
     // (one slab per XCD filled with L2-local fp64 atomics was measured 3x slower than slab + reduce)
-    r.slab = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nb * chunks * r.M * r.N * 8 + 64);
+    const int64_t nslab = (int64_t)nb * r.m_tiles * chunks;
+    r.slab = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nslab * r.M * r.N * 8 + 64);
     if (!r.slab) return TTSK_ERR_HIP;
     const int nmt = (int)cdiv(r.M, 16), nnt = (int)cdiv(r.N, 16);
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * nb * (double)d.M * (double)d.N * (double)K, 4, nmt * 10 + nnt, false, false);
     int rc;
-    if (nmt <= 4) rc = launch_skinny_r_0(r, nmt, nnt, chunks * nb, st);
-    else if (nmt <= 6) rc = launch_skinny_r_1(r, nmt, nnt, chunks * nb, st);
-    else if (nmt == 7) rc = launch_skinny_r_2(r, nmt, nnt, chunks * nb, st);
-    else rc = launch_skinny_r_3(r, nmt, nnt, chunks * nb, st);
+    if (nmt <= 4) rc = launch_skinny_r_0(r, nmt, nnt, (int)nslab, st);
+    else if (nmt <= 6) rc = launch_skinny_r_1(r, nmt, nnt, (int)nslab, st);
+    else if (nmt == 7) rc = launch_skinny_r_2(r, nmt, nnt, (int)nslab, st);
+    else rc = launch_skinny_r_3(r, nmt, nnt, (int)nslab, st);
     if (prof) prof_close(st);
     if (rc != TTSK_OK) return rc;
     const int64_t mn = (int64_t)r.M * r.N;
     ReduceOut ro{};
     for (int b = 0; b < nb; ++b) ro.C[b] = C[b];
-    hipLaunchKernelGGL(skinny_r_reduce, dim3((unsigned)cdiv(mn, 16), (unsigned)nb), dim3(256), 0, st, r.slab, chunks,
-                       r.M, r.N, ro, swap ? d.c_n : d.c_m, swap ? d.c_m : d.c_n, d.alpha, d.accumulate);
+    hipLaunchKernelGGL(skinny_r_reduce, dim3((unsigned)cdiv(mn, 16), (unsigned)(nb * r.m_tiles)), dim3(256), 0, st, r.slab,
+                       chunks, r.M, r.N, r.m_tiles, r.Mtot, ro, swap ? d.c_n : d.c_m, swap ? d.c_m : d.c_n, d.alpha,
+                       d.accumulate);
     TTSK_LAUNCH_CHECK();
     return 1;
 }
