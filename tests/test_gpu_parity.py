@@ -90,6 +90,10 @@ def test_chain_kernels_against_einsum(tsa):
         # long-K with the longer side cut into row tiles of 128 (dense unfoldings: 20 x K times K x 4096)
         ("kp,kq->pq", (6000, 300), (6000, 20)), ("kp,kq->pq", (4100, 18), (4100, 1000)),
         ("kp,kq->pq", (70000, 130), (70000, 64)), ("kp,kq->pq", (4096, 2), (4096, 4098)),
+        # long-K with k-contiguous ("generic") operands on either or both sides, odd extents
+        ("pk,kq->pq", (20, 50000), (50000, 64)), ("pk,qk->pq", (64, 40000), (40, 40000)),
+        ("kp,qk->pq", (9000, 300), (21, 9000)), ("pk,qk->pq", (37, 5003), (131, 5003)),
+        ("kp,kq->pq", (5001, 31), (5001, 29)),
     ]
     for spec, sa, sb in specs:
         A, B = rng.standard_normal(sa), rng.standard_normal(sb)

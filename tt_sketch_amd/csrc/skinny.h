@@ -44,6 +44,7 @@ struct SkinnyS {
     int64_t s_extent, w_extent, c_extent;   // elements addressable from each base (all < 2^29)
     double alpha;
     int accumulate;
+    int big;            // 1: 64-bit origins per row block / k-block / output tile (operands beyond 4 GB)
     long long *stamps;   // diagnostics (TTSK_SK_STAMPS): s_memtime at phase boundaries, 8 per workgroup
 };
 
@@ -60,12 +61,30 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     return (T *)(((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;   // beyond any num_records: loads return 0, stores are dropped
 
 // plain write-back stores: non-temporal and write-through (sc0 sc1) variants measured 10-35 % slower
 __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, uint32_t voff, double v)
 {
     __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<v2i_t *>(&v), r, (int)voff, 0, 0);
+}
+
+template <int NPT, int NT, bool SH, int D, int RB, bool BIG>
+__device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const double *Wl, const int v, const int tile0,
+                                                   const int tshared);
+
+template <int NPT, int NT, bool SH, int D, int RB>
+__device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl, const int v, const int tile0,
+                                              const int tshared)
+{
+    if (a.big) skinny_s_wave_impl<NPT, NT, SH, D, RB, true>(a, Wl, v, tile0, tshared);
+    else skinny_s_wave_impl<NPT, NT, SH, D, RB, false>(a, Wl, v, tile0, tshared);
 }
 
 // Stage W once per workgroup: Wl[k][m], zero beyond (K, P).  All loads of a thread are issued
@@ -112,9 +131,12 @@ __device__ __forceinline__ void skinny_s_stage(const SkinnyS &a, double *Wl)
 // rows: waves v and v+4 share row block 4g+v and split W's NPT column tiles ceil/floor; if SH,
 // the tiles of a fifth block are dealt one per wave.  For C3 (NPT = 7) that is 9,9,9,8 tile
 // strips on the four SIMDs and 1250 row blocks -> 250 workgroups = one round over 256 CUs.
-template <int NPT, int NT, bool SH, int D, int RB>
-__device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl, const int v, const int tile0,
-                                              const int tshared)
+// BIG: operands or outputs beyond the reach of one buffer descriptor + 32-bit offset (dense
+// unfoldings); see the comment at `Sp` below.  Two variants because rebuilding a descriptor per load
+// costs the rank-100 chain shapes 4-9 %.
+template <int NPT, int NT, bool SH, int D, int RB, bool BIG>
+__device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const double *Wl, const int v, const int tile0,
+                                                   const int tshared)
 {
     constexpr int LDW = ldmf(16 * NPT);
     constexpr int NTC = NT ? NT : 1;
@@ -122,8 +144,13 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
     const int x16 = lane & 15, kq = lane >> 4;
     const int KB = (a.K + 3) >> 2, ITER = (KB + D - 1) / D;
     const int prob = blockIdx.x / a.wpp, wg = blockIdx.x - prob * a.wpp;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(uniform_ptr(a.S[prob]), a.s_extent * 8);
-    const uint32_t kstep = (uint32_t)(4 * a.s_k * 8);
+    // Every load goes through a descriptor whose base is the origin of its row block and k-block
+    // (64-bit scalar arithmetic), the per-lane offset only spans 16 rows x 4 k: streamed operands and
+    // outputs of any size (a dense unfolding is 8.6 GB).  All masking is explicit, so the descriptors'
+    // own range is just the OOB_OFF sentinel.
+    const double *Sp = uniform_ptr(a.S[prob]);
+    const int64_t kstep = 4 * a.s_k;
+    const __amdgpu_buffer_rsrc_t rs_all = make_rsrc(Sp, a.s_extent * 8);      // !BIG: one descriptor, 32-bit offsets
     const int nkb_lane = (a.K - kq + 3) >> 2;          // k-blocks in which this lane's k = 4 kb + kq is < K
     const bool sh_on = SH && tshared < NPT;
 
@@ -139,24 +166,38 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
         in_off = (int64_t)u * a.s_u + (int64_t)vv * a.s_j;
         return (u < a.U && vv < a.V) ? (int64_t)u * a.c_u + (int64_t)vv * a.c_j : -1;
     };
-    auto lane_off = [&](int64_t rb) -> uint32_t {
+    // element offset of the first row of block rb (wave-uniform) ...
+    auto blk_org = [&](int64_t rb) -> int64_t {
+        if constexpr (!BIG) return 0;
+        int64_t in0;
+        (void)row_of(rb, 0, in0);
+        return uniform_i64(in0);
+    };
+    // ... and this lane's byte offset from it (OOB_OFF: row past the end)
+    auto lane_off = [&](int64_t rb, int64_t org) -> uint32_t {
         int64_t in_off;
         const int64_t j = row_of(rb, x16, in_off);
-        return j >= 0 ? (uint32_t)((in_off + (int64_t)kq * a.s_k) * 8) : OOB_OFF;
+        return j >= 0 ? (uint32_t)((in_off - org + (int64_t)kq * a.s_k) * 8) : OOB_OFF;
     };
     // masked lanes (k >= K, group past the end) read offset OOB_OFF = 0.0
-    auto fetch = [&](uint32_t base, int nkb, int kb) -> double {
-        return ld8(rs, (kb < nkb && base != OOB_OFF) ? base : OOB_OFF, (uint32_t)kb * kstep);
+    auto fetch = [&](int64_t org, uint32_t off, int nkb, int kb) -> double {
+        if constexpr (BIG) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Sp + org + (int64_t)kb * kstep, (int64_t)OOB_OFF);
+            return ld8(rs, (kb < nkb && off != OOB_OFF) ? off : OOB_OFF, 0);
+        } else {
+            return ld8(rs_all, (kb < nkb && off != OOB_OFF) ? off : OOB_OFF, (uint32_t)kb * (uint32_t)(kstep * 8));
+        }
     };
 
     int g = wg;
     int nkb = g < a.groups ? nkb_lane : 0;
-    uint32_t voA = lane_off((int64_t)g * RB + v), voB = lane_off((int64_t)g * RB + 4);
+    int64_t ogA = blk_org((int64_t)g * RB + v), ogB = blk_org((int64_t)g * RB + 4);
+    uint32_t voA = lane_off((int64_t)g * RB + v, ogA), voB = lane_off((int64_t)g * RB + 4, ogB);
     double ringA[D], ringB[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        if (NT) ringA[d] = fetch(voA, nkb, d);
-        if (SH) ringB[d] = fetch(voB, sh_on ? nkb : 0, d);
+        if (NT) ringA[d] = fetch(ogA, voA, nkb, d);
+        if (SH) ringB[d] = fetch(ogB, voB, sh_on ? nkb : 0, d);
     }
 
     skinny_s_stage<NPT, D>(a, const_cast<double *>(Wl));   // after the ring loads: both round trips overlap
@@ -175,7 +216,7 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
 #pragma unroll
     for (int t = 0; t < 4; ++t) accB[t] = 0.0;
 
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(uniform_ptr(a.C[prob]), a.c_extent * 8);
+    double *Cp = uniform_ptr(a.C[prob]);
     // acc[t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is D[4 beta + i][4((beta+t)&3) + j4]
     // (16x16x4 form: register t of lane l is D[4 t + (l >> 4)][l & 15])
     int e_m[4], e_j[4];
@@ -184,10 +225,9 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
         e_m[t] = TTSK_S_M16 ? 4 * t + (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
         e_j[t] = TTSK_S_M16 ? (lane & 15) : 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
     }
-    const uint32_t tile_step = (uint32_t)(16 * a.c_m * 8);
-
     while (g < a.groups) {
         uint32_t nA = voA, nB = voB;
+        int64_t ngA = ogA, ngB = ogB;
         int nkb_n = nkb;
         // K is padded to ITER * D k-blocks (zero rows of W, masked loads of S): one loop shape for
         // every iteration keeps the k-blocks overlapping across the whole group
@@ -196,8 +236,10 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
             if (itn == ITER) {
                 itn = 0;
                 const int gn = g + a.wpp;
-                nA = lane_off((int64_t)gn * RB + v);
-                nB = lane_off((int64_t)gn * RB + 4);
+                ngA = blk_org((int64_t)gn * RB + v);
+                ngB = blk_org((int64_t)gn * RB + 4);
+                nA = lane_off((int64_t)gn * RB + v, ngA);
+                nB = lane_off((int64_t)gn * RB + 4, ngB);
                 nkb_n = gn < a.groups ? nkb_lane : 0;
             }
 #pragma unroll
@@ -212,11 +254,11 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
                 const double sA = NT ? ringA[d] : 0.0, sB = SH ? ringB[d] : 0.0;
                 if (NT) {
                     if (!TTSK_S_M16) rot4(ringA[d], rA);
-                    ringA[d] = fetch(nA, nkb_n, itn * D + d);
+                    ringA[d] = fetch(ngA, nA, nkb_n, itn * D + d);
                 }
                 if (SH) {
                     if (!TTSK_S_M16) rot4(ringB[d], rB);
-                    ringB[d] = fetch(nB, sh_on ? nkb_n : 0, itn * D + d);
+                    ringB[d] = fetch(ngB, nB, sh_on ? nkb_n : 0, itn * D + d);
                 }
                 if (TTSK_S_M16) {
 #pragma unroll
@@ -235,22 +277,40 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
             }
         }
         SK_STAMP(3);
-        // epilogue: branch-free buffer stores, masked lanes go out of range
+        // epilogue: branch-free buffer stores, masked lanes go out of range; one descriptor per
+        // (row block, tile of W) whose base is the output element of the block's first row
         {
+            int64_t dummy;
+            const int64_t outA = BIG ? uniform_i64(row_of((int64_t)g * RB + v, 0, dummy)) : 0;
+            const int64_t outB = BIG ? uniform_i64(row_of((int64_t)g * RB + 4, 0, dummy)) : 0;
+            uint32_t offA[4], offB[4];       // this lane's byte offset inside a tile, per register
+            bool okA[4], okB[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t ja = row_of((int64_t)g * RB + v, e_j[t], dummy);
+                const int64_t jb = row_of((int64_t)g * RB + 4, e_j[t], dummy);
+                okA[t] = ja >= 0;
+                okB[t] = sh_on && jb >= 0;
+                offA[t] = (uint32_t)((ja - outA + (int64_t)e_m[t] * a.c_m) * 8);
+                offB[t] = (uint32_t)((jb - outB + (int64_t)e_m[t] * a.c_m) * 8);
+            }
+            __amdgpu_buffer_rsrc_t rcA[NTC], rcB;
+            const uint32_t tile_step = BIG ? 0u : (uint32_t)(16 * a.c_m * 8);      // !BIG: tiles by offset
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+                rcA[p] = BIG ? make_rsrc(Cp + (outA < 0 ? 0 : outA) + (int64_t)16 * (tile0 + p) * a.c_m, (int64_t)OOB_OFF)
+                             : make_rsrc(Cp, a.c_extent * 8);
+            rcB = BIG ? make_rsrc(Cp + (outB < 0 ? 0 : outB) + (int64_t)16 * tshared * a.c_m, (int64_t)OOB_OFF)
+                      : make_rsrc(Cp, a.c_extent * 8);
             uint32_t offs[NTC][4], offt[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                int64_t dummy;
-                const int64_t ja = row_of((int64_t)g * RB + v, e_j[t], dummy);
-                const int64_t jb = row_of((int64_t)g * RB + 4, e_j[t], dummy);
-                const uint32_t oa = (uint32_t)((ja + (int64_t)e_m[t] * a.c_m) * 8);
-                const uint32_t ob = (uint32_t)((jb + (int64_t)e_m[t] * a.c_m) * 8);
 #pragma unroll
                 for (int p = 0; p < NT; ++p) {
-                    offs[p][t] = (ja >= 0 && 16 * (tile0 + p) + e_m[t] < a.P) ? oa + (tile0 + p) * tile_step : OOB_OFF;
+                    offs[p][t] = (okA[t] && 16 * (tile0 + p) + e_m[t] < a.P) ? offA[t] + (tile0 + p) * tile_step : OOB_OFF;
                     accA[p][t] *= a.alpha;
                 }
-                offt[t] = (sh_on && jb >= 0 && 16 * tshared + e_m[t] < a.P) ? ob + tshared * tile_step : OOB_OFF;
+                offt[t] = (okB[t] && 16 * tshared + e_m[t] < a.P) ? offB[t] + tshared * tile_step : OOB_OFF;
                 accB[t] *= a.alpha;
             }
             if (a.accumulate) {
@@ -258,10 +318,10 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
 #pragma unroll
                 for (int p = 0; p < NT; ++p)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) old[p][t] = ld8(rc, offs[p][t], 0);
+                    for (int t = 0; t < 4; ++t) old[p][t] = ld8(rcA[p], offs[p][t], 0);
                 if (SH) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) olds[t] = ld8(rc, offt[t], 0);
+                    for (int t = 0; t < 4; ++t) olds[t] = ld8(rcB, offt[t], 0);
                 }
 #pragma unroll
                 for (int p = 0; p < NT; ++p)
@@ -276,13 +336,13 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
             for (int p = 0; p < NT; ++p)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    st8(rc, offs[p][t], accA[p][t]);
+                    st8(rcA[p], offs[p][t], accA[p][t]);
                     accA[p][t] = 0.0;
                 }
             if (SH) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    st8(rc, offt[t], accB[t]);
+                    st8(rcB, offt[t], accB[t]);
                     accB[t] = 0.0;
                 }
             }
@@ -291,6 +351,8 @@ __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl
         g += a.wpp;
         voA = nA;
         voB = nB;
+        ogA = ngA;
+        ogB = ngB;
         nkb = nkb_n;
     }
     if (a.stamps) {
@@ -355,6 +417,11 @@ struct SkinnyR {
     // addresses its operands from its own chunk / tile origin, so operands beyond 4 GB are fine.
     int m_tiles, rebase;
     int64_t Mtot;
+    // An operand whose rows are not contiguous, or not pairable (odd extent / stride, unaligned base),
+    // is "generic": plain 16-row tiles, one 8-byte load per tile and lane at row stride a_m / b_n,
+    // each tile through its own descriptor (the rows of a k-contiguous unfolding are 128 MB apart).
+    int a_gen, b_gen;
+    int64_t a_m, b_n;
     long long *stamps;
 };
 
@@ -365,8 +432,10 @@ __device__ __forceinline__ void st16(double *p, double x, double y)
 
 // Wave tile: rows [row0, row0 + 32 PA + 16 SA) x columns [col0, col0 + 32 PB + 16 SB):
 // PA / PB paired 32-blocks and an optional single 16-block per side.
-template <int PA, int SA, int PB, int SB, int D>
-__device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, const int col0)
+// NSUB > 1: the wave works on the sub-th of NSUB equal pieces of the workgroup's chunk (small
+// outputs: every wave owns the whole tile set and its own stretch of kappa, one slab per wave).
+template <int PA, int SA, int PB, int SB, int D, bool GEN, int NSUB>
+__device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int row0, const int col0, const int sub)
 {
     constexpr int TM = 2 * PA + SA, TN = 2 * PB + SB;
     const int lane = threadIdx.x & 63;
@@ -374,15 +443,17 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     SK_STAMP(0);
     const int pt = blockIdx.x / a.chunks, ci = blockIdx.x - pt * a.chunks;
     const int prob = pt / a.m_tiles, mtile = pt - prob * a.m_tiles;
-    const int64_t k0 = (int64_t)ci * a.chunk;
-    const int64_t len = a.K - k0 < a.chunk ? a.K - k0 : a.chunk;
-    const int nkb_lane = (int)((len - kq + 3) >> 2);
+    const int64_t piece = NSUB > 1 ? (((a.chunk + NSUB - 1) / NSUB + 3) & ~(int64_t)3) : a.chunk;
+    const int64_t k0 = (int64_t)ci * a.chunk + (NSUB > 1 ? sub * piece : 0);
+    const int64_t kend = ((int64_t)ci + 1) * a.chunk < a.K ? ((int64_t)ci + 1) * a.chunk : a.K;
+    const int64_t len = kend - k0 < 0 ? 0 : (kend - k0 < piece ? kend - k0 : piece);
+    const int nkb_lane = (int)(len > kq ? (len - kq + 3) >> 2 : 0);
     const int KB = (int)((len + 3) >> 2);
     const int64_t tile_row0 = (int64_t)mtile * a.M;                 // first row of this tile in A
     const int rows_here = (int)(a.Mtot - tile_row0 < a.M ? a.Mtot - tile_row0 : a.M);
     // operand origins of this workgroup (rebase: + the chunk's kappa offset; every out-of-range lane is
     // masked explicitly, the descriptor's own range check is then only the OOB_OFF sentinel)
-    const int64_t a_org = tile_row0 + (a.rebase ? k0 * a.a_ki : 0), b_org = a.rebase ? k0 * a.b_ki : 0;
+    const int64_t a_org = tile_row0 * (GEN ? a.a_m : 1) + (a.rebase ? k0 * a.a_ki : 0), b_org = a.rebase ? k0 * a.b_ki : 0;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(uniform_ptr(a.A[prob]) + a_org, a.rebase ? (int64_t)OOB_OFF : (a.a_extent - tile_row0) * 8);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(uniform_ptr(a.B[prob]) + b_org, a.rebase ? (int64_t)OOB_OFF : a.b_extent * 8);
 
@@ -404,24 +475,53 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     for (int q = 0; q < PB; ++q) colB[q] = col0 + 32 * q + 2 * x16 < a.N ? (uint32_t)(col0 + 32 * q + 2 * x16) * 8u : OOB_OFF;
     if (SB) colB[PB] = col0 + 32 * PB + x16 < a.N ? (uint32_t)(col0 + 32 * PB + x16) * 8u : OOB_OFF;
 
+    // generic operands: per-tile descriptors and validity
+    __amdgpu_buffer_rsrc_t raT[TM], rbT[TN];
+    bool okA[TM], okB[TN];
+    const uint32_t xA = (uint32_t)((int64_t)x16 * a.a_m * 8), xB = (uint32_t)((int64_t)x16 * a.b_n * 8);
+    if constexpr (GEN) {
+#pragma unroll
+    for (int p = 0; p < TM; ++p) {
+        raT[p] = make_rsrc(uniform_ptr(a.A[prob] + a_org + (int64_t)(row0 + 16 * p) * a.a_m),
+                           a.rebase ? (int64_t)OOB_OFF : (a.a_extent - tile_row0 * a.a_m - (int64_t)(row0 + 16 * p) * a.a_m) * 8);
+        okA[p] = row0 + 16 * p + x16 < rows_here;
+    }
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+        rbT[q] = make_rsrc(uniform_ptr(a.B[prob] + b_org + (int64_t)(col0 + 16 * q) * a.b_n),
+                           a.rebase ? (int64_t)OOB_OFF : (a.b_extent - (int64_t)(col0 + 16 * q) * a.b_n) * 8);
+        okB[q] = col0 + 16 * q + x16 < a.N;
+    }
+    }
+
     double ringA[D][TM], ringB[D][TN];
     int kb_load = 0;
     auto issue = [&](int d) {
         const bool ok = kb_load < nkb_lane;
+        if constexpr (GEN) {
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const double2 v = ld16(ra, (ok && rowA[p] != OOB_OFF) ? rowA[p] + offA : OOB_OFF, 0);
-            ringA[d][2 * p] = v.x;
-            ringA[d][2 * p + 1] = v.y;
-        }
-        if (SA) ringA[d][2 * PA] = ld8(ra, (ok && rowA[PA] != OOB_OFF) ? rowA[PA] + offA : OOB_OFF, 0);
+            for (int p = 0; p < TM; ++p) ringA[d][p] = ld8(raT[p], (ok && okA[p]) ? xA + offA : OOB_OFF, 0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-            const double2 v = ld16(rb, (ok && colB[q] != OOB_OFF) ? colB[q] + offB : OOB_OFF, 0);
-            ringB[d][2 * q] = v.x;
-            ringB[d][2 * q + 1] = v.y;
+            for (int p = 0; p < PA; ++p) {
+                const double2 v = ld16(ra, (ok && rowA[p] != OOB_OFF) ? rowA[p] + offA : OOB_OFF, 0);
+                ringA[d][2 * p] = v.x;
+                ringA[d][2 * p + 1] = v.y;
+            }
+            if (SA) ringA[d][2 * PA] = ld8(ra, (ok && rowA[PA] != OOB_OFF) ? rowA[PA] + offA : OOB_OFF, 0);
         }
-        if (SB) ringB[d][2 * PB] = ld8(rb, (ok && colB[PB] != OOB_OFF) ? colB[PB] + offB : OOB_OFF, 0);
+        if constexpr (GEN) {
+#pragma unroll
+            for (int q = 0; q < TN; ++q) ringB[d][q] = ld8(rbT[q], (ok && okB[q]) ? xB + offB : OOB_OFF, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const double2 v = ld16(rb, (ok && colB[q] != OOB_OFF) ? colB[q] + offB : OOB_OFF, 0);
+                ringB[d][2 * q] = v.x;
+                ringB[d][2 * q + 1] = v.y;
+            }
+            if (SB) ringB[d][2 * PB] = ld8(rb, (ok && colB[PB] != OOB_OFF) ? colB[PB] + offB : OOB_OFF, 0);
+        }
         ++kb_load;
         ki += 4;
         offA += stepA;
@@ -477,24 +577,33 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     // acc[p][q][t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is fragment element
     // (r = 4 beta + i, c = 4((beta+t)&3) + j4); pair fragments 2p / 2p+1 are rows 32p + 2r + {0,1}
     // (16x16x4 form: register t of lane l is fragment element (r = 4 t + (l >> 4), c = l & 15))
-    double *slab = a.slab + (int64_t)blockIdx.x * a.M * a.N;
+    double *slab = a.slab + ((int64_t)blockIdx.x * NSUB + sub) * a.M * a.N;
 #pragma unroll
     for (int p = 0; p < TM; ++p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int r16 = TTSK_R_M16 ? 4 * t + (lane >> 4) : 4 * ((lane >> 2) & 3) + (lane >> 4);
             const int c16 = TTSK_R_M16 ? (lane & 15) : 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3);
-            const int m = p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16;
+            const int m = GEN ? row0 + 16 * p + r16
+                                  : (p < 2 * PA ? row0 + 32 * (p >> 1) + 2 * r16 + (p & 1) : row0 + 32 * PA + r16);
             if (m < rows_here) {
                 double *srow = slab + (int64_t)m * a.N;
+                if constexpr (GEN) {
 #pragma unroll
-                for (int q = 0; q < PB; ++q) {
-                    const int n = col0 + 32 * q + 2 * c16;     // even N (16-byte loads) => n + 1 < N too
-                    if (n < a.N) st16(srow + n, acc[p][2 * q][t], acc[p][2 * q + 1][t]);
-                }
-                if (SB) {
-                    const int n = col0 + 32 * PB + c16;
-                    if (n < a.N) srow[n] = acc[p][2 * PB][t];
+                    for (int q = 0; q < TN; ++q) {
+                        const int n = col0 + 16 * q + c16;
+                        if (n < a.N) srow[n] = acc[p][q][t];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) {
+                        const int n = col0 + 32 * q + 2 * c16;     // even N (16-byte loads) => n + 1 < N too
+                        if (n < a.N) st16(srow + n, acc[p][2 * q][t], acc[p][2 * q + 1][t]);
+                    }
+                    if (SB) {
+                        const int n = col0 + 32 * PB + c16;
+                        if (n < a.N) srow[n] = acc[p][2 * PB][t];
+                    }
                 }
             }
         }
@@ -506,6 +615,17 @@ __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, 
     }
 }
 
+template <int PA, int SA, int PB, int SB, int D, int NSUB = 1>
+__device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, const int col0, const int sub = 0)
+{
+    // two straight-line variants (a branch inside the k-block loop would break its software pipeline)
+    if (a.a_gen) skinny_r_wave_impl<PA, SA, PB, SB, D, true, NSUB>(a, row0, col0, sub);
+    else skinny_r_wave_impl<PA, SA, PB, SB, D, false, NSUB>(a, row0, col0, sub);
+}
+
+// outputs of at most SKR_KSPLIT_TILES tiles: kappa split over the 8 waves instead of the tiles
+constexpr int SKR_KSPLIT_TILES = 12;
+
 // 8 waves over the (<= 8) x (<= 8) tiles of the output: 2 row halves x 4 column strips, or -- when
 // there are at most 4 column tiles -- 4 row quarters x 2 column strips, which keeps all waves busy
 // and needs 2 instead of 3 loads per 4 tiles on the narrow shapes (left chain: 7 x 4 tiles).
@@ -513,7 +633,10 @@ template <int NMT, int NNT, int D>
 __global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
 {
     const int w = threadIdx.x >> 6, s = w & 3, h = w >> 2;
-    if constexpr (NNT <= 4) {
+    if constexpr (NMT * NNT <= SKR_KSPLIT_TILES) {
+        // no operand is loaded twice and 7 loads feed 12 tiles instead of 2 feeding 1
+        skinny_r_wave<NMT / 2, NMT % 2, NNT / 2, NNT % 2, D, 8>(a, 0, 0, w);
+    } else if constexpr (NNT <= 4) {
         constexpr int TQ = (NMT + 3) / 4;                    // row tiles per quarter (1 or 2)
         constexpr int TS = (NNT + 1) / 2;                    // column tiles per strip (1 or 2)
         const int rows = NMT - s * TQ < TQ ? NMT - s * TQ : TQ;          // <= 0: nothing for this wave

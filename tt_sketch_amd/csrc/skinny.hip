@@ -115,22 +115,28 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     const int64_t K = d.Ko * d.Ki;
     if ((d.M > 128 && d.N > 128) || K < 4096) return 0;
     if (d.Ko > 1 && d.Ki < 4) return 0;
-    if (d.a_m != 1 || d.b_n != 1 || d.a_ko < 0 || d.a_ki < 0 || d.b_ko < 0 || d.b_ki < 0) return 0;
-    if ((d.M | d.N | d.a_ko | d.a_ki | d.b_ko | d.b_ki) & 1) return 0;
-    for (int b = 0; b < nb; ++b)
-        if (((uintptr_t)A[b] | (uintptr_t)B[b]) & 15) return 0;
+    if (d.a_m < 0 || d.b_n < 0 || d.a_ko < 0 || d.a_ki < 0 || d.b_ko < 0 || d.b_ki < 0) return 0;
+    // pairable = contiguous rows, even extent / strides, 16-byte aligned base; otherwise generic tiles
+    bool a_pair = d.a_m == 1 && !((d.M | d.a_ko | d.a_ki) & 1), b_pair = d.b_n == 1 && !((d.N | d.b_ko | d.b_ki) & 1);
+    for (int b = 0; b < nb; ++b) {
+        if ((uintptr_t)A[b] & 15) a_pair = false;
+        if ((uintptr_t)B[b] & 15) b_pair = false;
+    }
     SkinnyR r{};
     r.nb = nb;
     // the operand with more 16-row tiles plays "A" (rows, tiled by 128 when longer), the other "B"
     const bool swap = cdiv(d.N, 16) > cdiv(d.M, 16);
     int64_t big, small_;
     if (!swap) {
-        r.a_ko = d.a_ko; r.a_ki = d.a_ki; big = d.M;
-        r.b_ko = d.b_ko; r.b_ki = d.b_ki; small_ = d.N;
+        r.a_ko = d.a_ko; r.a_ki = d.a_ki; big = d.M; r.a_m = d.a_m; r.a_gen = !a_pair;
+        r.b_ko = d.b_ko; r.b_ki = d.b_ki; small_ = d.N; r.b_n = d.b_n; r.b_gen = !b_pair;
     } else {
-        r.a_ko = d.b_ko; r.a_ki = d.b_ki; big = d.N;
-        r.b_ko = d.a_ko; r.b_ki = d.a_ki; small_ = d.M;
+        r.a_ko = d.b_ko; r.a_ki = d.b_ki; big = d.N; r.a_m = d.b_n; r.a_gen = !b_pair;
+        r.b_ko = d.a_ko; r.b_ki = d.a_ki; small_ = d.M; r.b_n = d.a_m; r.b_gen = !a_pair;
     }
+    if (r.a_gen || r.b_gen) r.a_gen = r.b_gen = 1;     // one generic variant: both sides through plain tiles
+    // a lane's row offset inside a tile (15 rows) has to fit 32 bits next to the kappa walk
+    if (15 * r.a_m * 8 >= (1ll << 31) || 15 * r.b_n * 8 >= (1ll << 31)) return 0;
     r.Mtot = big;
     r.M = (int)(big < 128 ? big : 128);
     r.m_tiles = (int)cdiv(big, 128);
@@ -146,8 +152,8 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     if (d.Ko > 1 && r.a_ko == d.Ki * r.a_ki && r.b_ko == d.Ki * r.b_ki) r.Ki = K;   // uniform walk
     r.rebase = r.Ki == K ? 1 : 0;
     { const char *e = getenv("TTSK_SK_STAMPS"); r.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
-    r.a_extent = (big - 1) + (d.Ko - 1) * r.a_ko + (d.Ki - 1) * r.a_ki + 1;
-    r.b_extent = (r.N - 1) + (d.Ko - 1) * r.b_ko + (d.Ki - 1) * r.b_ki + 1;
+    r.a_extent = (big - 1) * r.a_m + (d.Ko - 1) * r.a_ko + (d.Ki - 1) * r.a_ki + 1;
+    r.b_extent = (r.N - 1) * r.b_n + (d.Ko - 1) * r.b_ko + (d.Ki - 1) * r.b_ki + 1;
     const int cus = num_cu() / nb > 0 ? num_cu() / nb : 1;
     const int64_t want_chunks = cus / r.m_tiles > 0 ? cus / r.m_tiles : 1;
     r.chunk = cdiv(cdiv(K, want_chunks), 4) * 4;
@@ -156,7 +162,8 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
         // per-workgroup origins: 32-bit offsets only have to span one chunk and one row tile; shorter
         // chunks when a kappa row is so long (an unfolding with 2 MB rows) that a chunk would not fit
         auto span = [&](int64_t chunk) {
-            const int64_t sa = (144 + (chunk + 64) * r.a_ki) * 8, sb = (144 + (chunk + 64) * r.b_ki) * 8;
+            const int64_t sa = ((r.a_gen ? 16 * r.a_m : 144) + (chunk + 64) * r.a_ki) * 8;
+            const int64_t sb = ((r.b_gen ? 16 * r.b_n : 144) + (chunk + 64) * r.b_ki) * 8;
             return sa > sb ? sa : sb;
         };
         while (span(r.chunk) >= (1ll << 32) - 64 && r.chunk > 64) r.chunk = cdiv(r.chunk / 2, 4) * 4;
@@ -167,15 +174,16 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     if ((int64_t)nb * r.m_tiles * chunks > (1 << 30) / 8) return 0;
     if (!r.rebase) {
         // 32-bit byte offsets including the kappa walk past the end of the last chunk
-        const int64_t reach_a = (big + 144 + (d.Ko + 1) * r.a_ko + (d.Ki + 64) * r.a_ki) * 8;
-        const int64_t reach_b = (144 + (d.Ko + 1) * r.b_ko + (d.Ki + 64) * r.b_ki) * 8;
+        const int64_t reach_a = ((r.a_gen ? 16 * r.a_m : big + 144) + (d.Ko + 1) * r.a_ko + (d.Ki + 64) * r.a_ki) * 8;
+        const int64_t reach_b = ((r.b_gen ? 16 * r.b_n : 144) + (d.Ko + 1) * r.b_ko + (d.Ki + 64) * r.b_ki) * 8;
         if (reach_a >= (1ll << 32) - 64 || reach_b >= (1ll << 32) - 64) return 0;
     }
     // (one slab per XCD filled with L2-local fp64 atomics was measured 3x slower than slab + reduce)
-    const int64_t nslab = (int64_t)nb * r.m_tiles * chunks;
-    r.slab = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nslab * r.M * r.N * 8 + 64);
-    if (!r.slab) return TTSK_ERR_HIP;
     const int nmt = (int)cdiv(r.M, 16), nnt = (int)cdiv(r.N, 16);
+    const int nsub = nmt * nnt <= SKR_KSPLIT_TILES ? 8 : 1;      // small outputs: one slab per wave
+    const int64_t nslab = (int64_t)nb * r.m_tiles * chunks;
+    r.slab = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nslab * nsub * r.M * r.N * 8 + 64);
+    if (!r.slab) return TTSK_ERR_HIP;
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * nb * (double)d.M * (double)d.N * (double)K, 4, nmt * 10 + nnt, false, false);
     int rc;
@@ -189,7 +197,7 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     ReduceOut ro{};
     for (int b = 0; b < nb; ++b) ro.C[b] = C[b];
     hipLaunchKernelGGL(skinny_r_reduce, dim3((unsigned)cdiv(mn, 16), (unsigned)(nb * r.m_tiles)), dim3(256), 0, st, r.slab,
-                       chunks, r.M, r.N, r.m_tiles, r.Mtot, ro, swap ? d.c_n : d.c_m, swap ? d.c_m : d.c_n, d.alpha,
+                       chunks * nsub, r.M, r.N, r.m_tiles, r.Mtot, ro, swap ? d.c_n : d.c_m, swap ? d.c_m : d.c_n, d.alpha,
                        d.accumulate);
     TTSK_LAUNCH_CHECK();
     return 1;
@@ -251,10 +259,14 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     s.w_extent = (K - 1) * s.w_k + (s.P - 1) * s.w_m + 1;
     s.c_u = d.batch == 1 ? 0 : d.c_b;
     s.c_extent = (s.P - 1) * s.c_m + (d.batch - 1) * s.c_u + ((int64_t)(d.batch == 1 ? s.J : s.V) - 1) * s.c_j + 1;
-    // 32-bit byte offsets, including the rows of the last (partial) group and the padded k-blocks
+    // per-lane 32-bit byte offsets only span one row block (16 rows, 4 k) and one output tile (16 x 16)
+    const int64_t span_s = (16 * s.s_j + 4 * s.s_k) * 8, span_c = (16 * s.c_j + 16 * s.c_m) * 8;
+    if (span_s >= (1ll << 32) - 64 || span_c >= (1ll << 32) - 64 || s.w_extent * 8 >= (1ll << 31)) return 0;
+    // everything within reach of one descriptor + 32-bit offsets (incl. the last partial group and the
+    // padded k-blocks)?  Otherwise the variant with 64-bit origins.
     const int64_t reach = ((d.batch + 4) * s.s_u + ((int64_t)s.V + 96) * s.s_j + (K + 24) * s.s_k) * 8;
     const int64_t reach_c = ((d.batch + 4) * s.c_u + ((int64_t)(d.batch == 1 ? s.J : s.V) + 96) * s.c_j + 144 * s.c_m) * 8;
-    if (reach >= (1ll << 32) - 64 || reach_c >= (1ll << 32) - 64 || s.w_extent * 8 >= (1ll << 31)) return 0;
+    s.big = (reach >= (1ll << 32) - 64 || reach_c >= (1ll << 32) - 64) ? 1 : 0;
     const int npt = (int)cdiv(s.P, 16);
     if ((size_t)((cdiv(K, 4) + 4) * 4 * ldmf(16 * npt) + 16) * 8 + 2048 > 160 * 1024) return 0;
     const bool prof = prof_on();
