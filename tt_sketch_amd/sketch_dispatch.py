@@ -148,6 +148,16 @@ class SketchMethod(enum.Enum):
 def general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
                           method: SketchMethod) -> Tuple[List[DevArray], List[DevArray]]:
     """The sketch as device arrays ``(Psi_cores, Omega_mats)`` (reference :202-275)."""
+    from .sketching_methods import dense_sketch
+    dense_sketch.clear_shared()
+    try:
+        return _general_sketch_device(tensor, left_drm, right_drm, method)
+    finally:
+        dense_sketch.clear_shared()
+
+
+def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
+                           method: SketchMethod) -> Tuple[List[DevArray], List[DevArray]]:
     d = len(tensor.shape)
     tensor.prepare_device()
     if method != SketchMethod.hmt:
