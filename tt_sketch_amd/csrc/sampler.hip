@@ -141,6 +141,34 @@ __device__ double ndtri_dev(double y0)
     return code ? -x : x;
 }
 
+// ndtri over a workgroup's 256 samples.  27 % of uniform samples fall in the tails of ndtri (two
+// software logs, a square root, three divisions), so practically every wave would execute both
+// branches for all its lanes.  Instead the central branch is evaluated in place and the tail samples
+// are compacted into an LDS queue and evaluated by the first threads of the workgroup: only full
+// waves of tail samples pay for the tail code.  Arithmetic per sample is unchanged (bit-identical).
+// All 256 threads must call this together; `live` = this thread has a sample.
+__device__ __forceinline__ void ndtri_block(bool live, double u, size_t g, double scale, double *__restrict__ out)
+{
+    __shared__ double q_u[256];
+    __shared__ size_t q_g[256];
+    __shared__ int q_n;
+    const double expm2 = 0.13533528323661269189;
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    const bool central = live && u > expm2 && u <= 1.0 - expm2;
+    if (central) {
+        out[g] = scale * ndtri_dev(u);
+    } else if (live) {
+        const int slot = atomicAdd(&q_n, 1);
+        q_u[slot] = u;
+        q_g[slot] = g;
+    }
+    __syncthreads();
+    const int n = q_n;
+    if ((int)threadIdx.x < n) out[q_g[threadIdx.x]] = scale * ndtri_dev(q_u[threadIdx.x]);
+    __syncthreads();
+}
+
 __global__ void hash_kernel(uint64_t *v, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -154,12 +182,53 @@ __global__ void sample_kernel(const int64_t *__restrict__ idx, IndexMap im, size
                               int rank, uint64_t seed, double *__restrict__ out)
 {
     const size_t tot = N * (size_t)rank;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < tot;
-         g += (size_t)gridDim.x * blockDim.x) {
-        size_t e = g / rank;
-        int j = (int)(g - e * rank);
-        uint64_t bits = rand_bits(flat_index(idx, im, e), rank_min + j, seed);
-        out[g] = MODE == 0 ? __longlong_as_double(bits) : ndtri_dev(mant_unit(bits));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // uniform trip count per workgroup (ndtri_block has barriers)
+    for (size_t g0 = (size_t)blockIdx.x * blockDim.x; g0 < tot; g0 += stride) {
+        const size_t g = g0 + threadIdx.x;
+        const bool live = g < tot;
+        uint64_t bits = 0;
+        if (live) {
+            size_t e = g / rank;
+            int j = (int)(g - e * rank);
+            bits = rand_bits(flat_index(idx, im, e), rank_min + j, seed);
+        }
+        if (MODE == 0) {
+            if (live) out[g] = __longlong_as_double(bits);
+        } else {
+            ndtri_block(live, live ? mant_unit(bits) : 0.5, g, 1.0, out);
+        }
+    }
+}
+
+// Same samples, one thread per index row (rank <= 32): the flat index and the column salts are
+// computed once per row / per workgroup instead of once per sample, and there is no 64-bit division;
+// the 256 x rank tile goes through LDS so that the store is contiguous.  ~2.5x fewer integer
+// instructions per sample than sample_kernel, which remains for wider ranks.
+template <int MODE>
+__global__ __launch_bounds__(256) void sample_rows_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t N,
+                                                          int rank_min, int rank, uint64_t seed,
+                                                          double *__restrict__ out)
+{
+    extern __shared__ double tile[];                         // [256][rank] + rank salts
+    uint64_t *salt = (uint64_t *)(tile + 256 * rank);
+    const int tid = threadIdx.x;
+    if (tid < rank) salt[tid] = mix64((uint64_t)(rank_min + tid)) + seed;
+    __syncthreads();
+    for (size_t e0 = (size_t)blockIdx.x * 256; e0 < N; e0 += (size_t)gridDim.x * 256) {
+        const size_t e = e0 + tid;
+        const bool live = e < N;
+        const uint64_t flat = live ? flat_index(idx, im, e) : 0;
+        for (int j = 0; j < rank; ++j) {
+            const uint64_t h = mix64(flat + salt[j]);
+            const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
+            if (MODE == 0) tile[tid * rank + j] = __longlong_as_double(bits);
+            else ndtri_block(live, live ? mant_unit(bits) : 0.5, (size_t)(tid * rank + j), 1.0, tile);
+        }
+        __syncthreads();
+        const size_t cnt = (N - e0 < 256 ? N - e0 : 256) * (size_t)rank;
+        for (size_t t = tid; t < cnt; t += 256) out[e0 * rank + t] = tile[t];
+        __syncthreads();
     }
 }
 
@@ -193,13 +262,14 @@ __global__ void sign_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t
 
 __global__ void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const size_t i = i0 + threadIdx.x;
         uint64_t h = mix64((uint64_t)i + key);
         h = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
         double u = mant_unit(h);
         if (u == 0.0) u = 0x1p-53;
-        out[i] = scale * ndtri_dev(u);
+        ndtri_block(i < n, u, i, scale, out);
     }
 }
 
@@ -208,6 +278,21 @@ static unsigned grid_for(size_t n, unsigned block = 256, unsigned cap = 16384)
     size_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
     return (unsigned)(b > cap ? cap : b);
+}
+
+template <int MODE>
+static void launch_sample(const int64_t *idx, const IndexMap &im, size_t N, int rank_min, int w, uint64_t seed,
+                          double *out, hipStream_t st)
+{
+    if (w <= 32) {
+        size_t blocks = (N + 255) / 256;
+        if (blocks > (1u << 16)) blocks = 1u << 16;
+        hipLaunchKernelGGL((sample_rows_kernel<MODE>), dim3((unsigned)blocks), dim3(256), (size_t)(256 * w + w) * 8, st,
+                           idx, im, N, rank_min, w, seed, out);
+    } else {
+        hipLaunchKernelGGL((sample_kernel<MODE>), dim3(grid_for(N * (size_t)w, 256, 1u << 20)), dim3(256), 0, st, idx,
+                           im, N, rank_min, w, seed, out);
+    }
 }
 
 template <typename OUT>
@@ -262,8 +347,7 @@ int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int
     if (rc) return rc;
     size_t tot = N * (size_t)(rank_max - rank_min);
     if (tot == 0) return TTSK_OK;
-    hipLaunchKernelGGL((sample_kernel<1>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, dev_idx,
-                       im, N, rank_min, rank_max - rank_min, seed, dev_out);
+    launch_sample<1>(dev_idx, im, N, rank_min, rank_max - rank_min, seed, dev_out, st);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
@@ -300,11 +384,9 @@ static int host_sample(const void *host_idx, const uint64_t *shape, int m, size_
     int status = TTSK_OK;
     if (e == hipSuccess) {
         if (mode == 0)
-            hipLaunchKernelGGL((sample_kernel<0>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, didx,
-                               im, N, rank_min, w, seed, (double *)dout);
+            launch_sample<0>(didx, im, N, rank_min, w, seed, (double *)dout, st);
         else if (mode == 1)
-            hipLaunchKernelGGL((sample_kernel<1>), dim3(grid_for(tot, 256, 1u << 20)), dim3(256), 0, st, didx,
-                               im, N, rank_min, w, seed, (double *)dout);
+            launch_sample<1>(didx, im, N, rank_min, w, seed, (double *)dout, st);
         else
             status = sign_dev<int16_t>(didx, im, N, true_rank, rank_min, rank_max, nnz, seed, (int16_t *)dout, st, 0);
         e = hipGetLastError();
