@@ -70,12 +70,15 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
                                                          const double *__restrict__ Rv, int64_t r, int64_t n,
                                                          double *__restrict__ psi, size_t chunk)
 {
+    // The inner loop is LDS-bandwidth bound (one read per operand and output pair), so the staged
+    // panel holds val * L (one read instead of two) and the slice boundaries of a batch are a 64-bit
+    // mask in scalar registers instead of a per-element index read.
     constexpr int TB = 64;  // nonzeros staged per LDS batch
     extern __shared__ double sm[];
-    double *sL = sm;                 // TB * l
+    double *sL = sm;                 // TB * l, already scaled by the entry
     double *sR = sL + TB * l;        // TB * r
-    double *sV = sR + TB * r;        // TB
-    int64_t *sK = (int64_t *)(sV + TB);
+    int64_t *sK = (int64_t *)(sR + TB * r);
+    __shared__ unsigned long long s_change;   // bit t: nonzero t of the batch starts a new slice
     const size_t beg = (size_t)blockIdx.x * chunk;
     const size_t end = beg + chunk < N ? beg + chunk : N;
     const int64_t pairs = l * r;
@@ -88,15 +91,19 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
         for (size_t b0 = beg; b0 < end; b0 += TB) {
             const int cnt = (int)((end - b0) < TB ? (end - b0) : TB);
             __syncthreads();
-            for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-                size_t e = perm ? (size_t)perm[b0 + t] : b0 + t;
-                sV[t] = val[e];
-                sK[t] = idx ? idx[e] : 0;
+            if (threadIdx.x < TB) {
+                const int t = threadIdx.x;
+                int64_t k = -2;
+                if (t < cnt) {
+                    const size_t e = perm ? (size_t)perm[b0 + t] : b0 + t;
+                    k = idx ? idx[e] : 0;
+                }
+                sK[t] = k;
             }
             for (int64_t t = threadIdx.x; t < (int64_t)cnt * l; t += blockDim.x) {
                 int64_t w = t / l, a2 = t - w * l;
                 size_t e = perm ? (size_t)perm[b0 + w] : b0 + w;
-                sL[t] = Lv ? Lv[e * l + a2] : 1.0;
+                sL[t] = val[e] * (Lv ? Lv[e * l + a2] : 1.0);
             }
             for (int64_t t = threadIdx.x; t < (int64_t)cnt * r; t += blockDim.x) {
                 int64_t w = t / r, c2 = t - w * r;
@@ -104,15 +111,32 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
                 sR[t] = Rv ? Rv[e * r + c2] : 1.0;
             }
             __syncthreads();
+            if (threadIdx.x < 64) {     // first wave: where does the slice index change inside the batch?
+                const int t = threadIdx.x;
+                const bool chg = t < cnt && t > 0 && sK[t] != sK[t - 1];
+                const unsigned long long m = __ballot(chg);
+                if (t == 0) s_change = m;
+            }
+            __syncthreads();
             if (live) {
-                for (int t = 0; t < cnt; ++t) {
-                    int64_t k = sK[t];
-                    if (k != cur) {
-                        if (cur >= 0 && acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
-                        acc = 0.0;
-                        cur = k;
+                const unsigned long long change = s_change;
+                const int64_t k0 = sK[0];
+                if (k0 != cur) {
+                    if (cur >= 0 && acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
+                    acc = 0.0;
+                    cur = k0;
+                }
+                if (change == 0) {                    // the usual case: the whole batch is one slice
+                    for (int t = 0; t < cnt; ++t) acc = fma(sL[t * l + a], sR[t * r + c], acc);
+                } else {
+                    for (int t = 0; t < cnt; ++t) {
+                        if ((change >> t) & 1) {
+                            if (acc != 0.0) unsafeAtomicAdd(&psi[(a * n + cur) * r + c], acc);
+                            acc = 0.0;
+                            cur = sK[t];
+                        }
+                        acc = fma(sL[t * l + a], sR[t * r + c], acc);
                     }
-                    acc = fma(sV[t] * sL[t * l + a], sR[t * r + c], acc);
                 }
             }
         }
@@ -210,7 +234,7 @@ int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int
     TTSK_ARG(l >= 1 && r >= 1 && n >= 1, "ttsk_sparse_psi: bad shape");
     TTSK_ARG(dev_idx_row || n == 1, "ttsk_sparse_psi: a NULL index row means a single slice (n = 1)");
     if (N == 0) return TTSK_OK;
-    const size_t lds = (size_t)64 * (l + r + 2) * 8;
+    const size_t lds = (size_t)64 * (l + r + 1) * 8;
     TTSK_ARG(lds <= 64 * 1024, "ttsk_sparse_psi: l + r = %lld too large for the staging buffer",
              (long long)(l + r));
     size_t chunk = 4096;
