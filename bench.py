@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--batch", type=int, default=8, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
+    ap.add_argument("--batch", type=int, default=16, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent sketches in flight (items of the tensor stream are issued on alternating "

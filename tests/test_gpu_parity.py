@@ -468,7 +468,7 @@ def test_sum_slices(tsa):
 
 def test_batched_one_call_path(tsa):
     """ttsk_tt_sketch_batch: nb tensors of one signature in one pass give, tensor by tensor, the
-    sketch of the single-tensor call and of the oracle (rank slices included; nb > 8 is sliced)."""
+    sketch of the single-tensor call and of the oracle (rank slices included; nb > 32 is sliced)."""
     import ctypes
     from tt_sketch_amd import tt_fused
     from tests.gpu_build import make_drm, make_tensor
@@ -479,7 +479,7 @@ def test_batched_one_call_path(tsa):
                                      # ranks (streamed kernel with tails, generic split-K for GEMM2)
                                      ((150, 160, 150, 140), (30, 32, 28), (26, 24, 22), (28, 30, 34), 3),
                                      ((150, 151, 149), (31, 29), (25, 27), (33, 35), 2),
-                                     ((5, 4, 6), (3, 2), (2, 3), (4, 3), 11)]:
+                                     ((5, 4, 6), (3, 2), (2, 3), (4, 3), 35)]:
         ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
         if len(shape) == 5:
             ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)

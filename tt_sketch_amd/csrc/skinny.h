@@ -18,7 +18,7 @@
 
 namespace ttsk {
 
-constexpr int SK_MAXB = 8;   // problems of one shape per launch (one tensor of a batch each)
+constexpr int SK_MAXB = 32;  // problems of one shape per launch (one tensor of a batch each)
 
 #ifndef TTSK_S_M16
 #define TTSK_S_M16 1

@@ -187,6 +187,8 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * nb * (double)d.M * (double)d.N * (double)K, 4, nmt * 10 + nnt, false, false);
     int rc;
+    // (a chunk -> XCD mapping that makes all problems of a batch fetch the shared operand into one L2
+    // halved the L2-fabric traffic of the batched GEMM2 but not its time)
     if (nmt <= 4) rc = launch_skinny_r_0(r, nmt, nnt, (int)nslab, st);
     else if (nmt <= 6) rc = launch_skinny_r_1(r, nmt, nnt, (int)nslab, st);
     else if (nmt == 7) rc = launch_skinny_r_2(r, nmt, nnt, (int)nslab, st);

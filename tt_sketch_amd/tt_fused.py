@@ -19,7 +19,7 @@ from .drm.tensor_train_drm import TensorTrainDRM
 from .tensor import TensorSum, TensorTrain
 
 _I64 = ctypes.c_int64
-MAX_BATCH = 8   # tensors per batched pass (SK_MAXB in csrc/skinny.h)
+MAX_BATCH = 32   # tensors per batched pass (SK_MAXB in csrc/skinny.h)
 
 
 class TTSketchPlan:
