@@ -84,3 +84,31 @@ def test_no_cpu_fallback_without_gpu():
     X = tsa.TensorTrain.random((4, 5, 6), 2, seed=1)
     with pytest.raises(nat.TtskError):
         tsa.stream_sketch(X, 2, 3, seed=1)
+
+
+def test_read_tns(tmp_path):
+    """FROSTT text format (reference scripts/frostt.py:51-65): 1-based indices, value last."""
+    import gzip
+    from tt_sketch_amd.io import read_tns
+    text = "# comment\n1 2 3 0.5\n4 1 2 -1.25\n\n2 2 2 3e-2\n"
+    p = tmp_path / "t.tns"
+    p.write_text(text)
+    T = read_tns(str(p))
+    assert T.shape == (4, 2, 3) and T.indices.shape == (3, 3)
+    assert np.array_equal(T.indices, np.array([[0, 3, 1], [1, 0, 1], [2, 1, 1]]))
+    assert np.allclose(T.entries, [0.5, -1.25, 0.03])
+    g = tmp_path / "t.tns.gz"
+    with gzip.open(g, "wb") as f:
+        f.write(text.encode())
+    T2 = read_tns(str(g), shape=(5, 5, 5))
+    assert T2.shape == (5, 5, 5) and np.array_equal(T2.indices, T.indices)
+    with pytest.raises(ValueError):
+        read_tns(str(p), shape=(2, 2, 2))
+    bad = tmp_path / "bad.tns"
+    bad.write_text("1 2 3 0.5\n1 2 0.5\n")
+    with pytest.raises(ValueError):
+        read_tns(str(bad))
+    zero = tmp_path / "zero.tns"
+    zero.write_text("0 1 1 1.0\n")
+    with pytest.raises(ValueError):
+        read_tns(str(zero))
