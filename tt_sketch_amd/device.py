@@ -27,7 +27,7 @@ _F64 = np.dtype(np.float64)
 # dense-tensor path allocates several per sketch and was swinging between 80 and 500 ms per call).
 # hipFree waits for the device; a recycled buffer gets the same guarantee by being handed out again
 # only after a device-wide ttsk_sync has happened since its release (nat.sync_epoch()).
-_POOL_MIN = 8 << 20          # bytes; smaller buffers go straight to ttsk_malloc / ttsk_free
+_POOL_MIN = 8 << 20          # bytes; below: the small-buffer pool further down
 _POOL_CAP = 48 << 30         # bytes kept at most
 _pool: "dict[int, list]" = {}   # rounded size -> [(release_epoch, ptr), ...]
 _pool_bytes = 0
@@ -63,28 +63,56 @@ def _pool_give(size: int, ptr: int) -> None:
         nat.lib().ttsk_free(ctypes.c_void_p(old))
 
 
+# Small buffers (the temporaries of the Python-level paths: 60 per orthogonal_sketch) are recycled
+# at once, by power-of-two size class: every hipFree is a device-wide wait (28 of the 35 ms of an
+# orthogonal_sketch at the north-star shape went there).  Immediate reuse is safe for stream-ordered
+# use, which is how DevArrays are used: the library's Python layer works on stream 0 (the one-call TT
+# path forks and joins its helper stream inside the call), and the one place that spreads arrays over
+# several streams (assemble_sketched_tt) holds them until it has synchronised.
+_SMALL_CAP = 2 << 30
+_small: "dict[int, list]" = {}
+_small_bytes = 0
+
+
+def _small_class(nbytes: int) -> int:
+    n = 256
+    while n < nbytes:
+        n <<= 1
+    return n
+
+
 class _Buffer:
-    """Owns one ttsk_malloc allocation (recycled through the pool above when large)."""
+    """Owns one ttsk_malloc allocation (recycled through the pools above)."""
     __slots__ = ("ptr", "nbytes", "_pooled")
 
     def __init__(self, nbytes: int):
+        global _small_bytes
         self.nbytes = int(nbytes)
-        self._pooled = 0
         if self.nbytes >= _POOL_MIN:
             self._pooled = _pool_round(self.nbytes)
             got = _pool_take(self._pooled)
+        else:
+            self._pooled = _small_class(self.nbytes)
+            lst = _small.get(self._pooled)
+            got = lst.pop() if lst else None
             if got is not None:
-                self.ptr = got
-                return
+                _small_bytes -= self._pooled
+        if got is not None:
+            self.ptr = got
+            return
         p = ctypes.c_void_p()
-        nat.call("ttsk_malloc", ctypes.byref(p), ctypes.c_size_t(max(self._pooled or self.nbytes, 8)))
+        nat.call("ttsk_malloc", ctypes.byref(p), ctypes.c_size_t(self._pooled))
         self.ptr = p.value
 
     def __del__(self):
+        global _small_bytes
         try:
             if self.ptr:
-                if self._pooled:
+                if self.nbytes >= _POOL_MIN:
                     _pool_give(self._pooled, self.ptr)
+                elif _small_bytes + self._pooled <= _SMALL_CAP:
+                    _small.setdefault(self._pooled, []).append(self.ptr)
+                    _small_bytes += self._pooled
                 else:
                     nat.lib().ttsk_free(ctypes.c_void_p(self.ptr))
         except Exception:  # interpreter shutdown
