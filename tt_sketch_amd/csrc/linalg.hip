@@ -269,22 +269,28 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         __syncthreads();
     }
     if (tid == 0) status[0] = (bad || rmin < cond_tol * rmax) ? 1 : 0;
-    // Rinv: column c by back substitution, one thread per column (its own column only)
+    // X = R^-1 (upper triangular), column c by back substitution, one thread per column.  X stays
+    // in LDS: its strict upper part X[i][c] (i < c) goes to the unused strict lower triangle of A
+    // at A[c][i], its diagonal to xd[] (a read-back from global memory per term made this loop 4x
+    // longer than the factorisation).
+    double *xd = sm + n * ld;
+    __syncthreads();
     for (int c = tid; c < n; c += 256) {
-        for (int i = n - 1; i > c; --i) Rinv[i * n + c] = 0.0;
-        Rinv[c * n + c] = 1.0 / A[c * ld + c];
+        xd[c] = 1.0 / A[c * ld + c];
         for (int i = c - 1; i >= 0; --i) {
-            double acc = 0.0;
-            for (int k = i + 1; k <= c; ++k) acc += A[i * ld + k] * Rinv[k * n + c];
-            Rinv[i * n + c] = -acc / A[i * ld + i];
+            double acc = A[i * ld + c] * xd[c];                       // k = c
+            for (int k = i + 1; k < c; ++k) acc += A[i * ld + k] * A[c * ld + k];   // X[k][c] at A[c][k]
+            A[c * ld + i] = -acc / A[i * ld + i];
         }
     }
+    __syncthreads();
+    auto X = [&](int i, int c) -> double { return i == c ? xd[c] : (i < c ? A[c * ld + i] : 0.0); };
+    for (int e = tid; e < n * n; e += 256) Rinv[e] = X(e / n, e % n);
     if (Ginv) {
-        __syncthreads();
         for (int e = tid; e < n * n; e += 256) {
             const int i = e / n, c = e % n, k0 = i > c ? i : c;
             double acc = 0.0;
-            for (int k = k0; k < n; ++k) acc += Rinv[i * n + k] * Rinv[c * n + k];
+            for (int k = k0; k < n; ++k) acc += X(i, k) * X(c, k);
             Ginv[e] = acc;
         }
     }
@@ -341,7 +347,7 @@ static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *
         TTSK_HIP(hipFuncSetAttribute((const void *)hh_sign_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)n * (n + 1) * 8, st, G, n, Rinv, Ginv, status, cond_tol);
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status, cond_tol);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
@@ -371,6 +377,9 @@ static int pinv_cholesky(const double *omega, int64_t l, int64_t r, double *pinv
     int host_status = 1;
     TTSK_HIP(hipMemcpyAsync(&host_status, status, sizeof(int), hipMemcpyDeviceToHost, st));
     TTSK_HIP(hipStreamSynchronize(st));
+    static int trace = [] { const char *e = getenv("TTSK_GEMM_TRACE"); return e ? atoi(e) : 0; }();
+    if (trace) fprintf(stderr, "ttsk_pinv %lld x %lld: normal equations %s\n", (long long)l, (long long)r,
+                       host_status ? "rejected -> Jacobi SVD" : "accepted");
     if (host_status) return 0;
     if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // Omega^T G^-1
     else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // G^-1 Omega^T
