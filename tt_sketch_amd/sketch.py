@@ -157,7 +157,9 @@ class SketchedTensorTrain(Tensor):
         return SketchedTensorTrain(self.sketch_.T, self.right_drm.T, self.left_drm.T)
 
     def to_tt(self) -> TensorTrain:
-        return TensorTrain(self.C_cores())
+        # device-resident cores: sketching or contracting the result again needs no PCIe round trip;
+        # every host-side TensorTrain method copies what it needs (tensor._host)
+        return TensorTrain(assemble_sketched_tt(self.sketch_, device=True))
 
     def to_numpy(self) -> npt.NDArray[np.float64]:
         return self.to_tt().to_numpy()
@@ -217,7 +219,7 @@ def nat_streams() -> int:
     return _native.NUM_STREAMS
 
 
-def assemble_sketched_tt(sketch: SketchContainer, direction="auto") -> ArrayList:
+def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool = False) -> ArrayList:
     """TT cores from a streaming sketch: C_mu = Psi_mu pinv(Omega_mu) ("right") or
     pinv(Omega_{mu-1}) Psi_mu ("left") (reference sketch.py:400-443)."""
     if direction == "auto":
@@ -248,6 +250,8 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto") -> ArrayList
     else:
         raise ValueError(f"Unknown direction {direction}")
     sync()
+    if device:          # cores stay on the device (TensorTrain copies them to the host on demand)
+        return [C if isinstance(C, DevArray) else as_dev(C) for C in pending]
     return [np.asarray(to_host(C)) for C in pending]
 
 
