@@ -199,6 +199,11 @@ int ttsk_sparse_sort_mode(const int64_t *dev_idx_row, size_t N, int64_t n, int64
  * contiguous; P is (r, l) contiguous.  The products A*P / P*B are ttsk_gemm calls. */
 int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
               int *host_rank /* may be NULL */, int stream);
+/* thin SVD of a small matrix (TensorTrain.round, tensor.py:446-484, after a QR has reduced the
+ * unfolding to its triangular factor): A (m, n) row-major, m >= n, n <= 1024, by one-sided Jacobi in
+ * one workgroup.  US (m, n) = U diag(S), S (n) descending, Vt (n, n); A = US Vt. */
+int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,
+                   int stream);
 /* thin QR of orth_step (sketch_dispatch.py:172, scipy.linalg.qr(mode="economic")):
  * A (m, n) row-major with m >= n is overwritten by Q (m, n); Householder with LAPACK's
  * sign convention.  R is not returned (the reference discards it). */

@@ -503,3 +503,34 @@ def test_batched_one_call_path(tsa):
             Psi, Om = plan.views(out[b * stride:b * stride + plan.size])
             for a, c in zip(Psi + Om, oP + oO):
                 assert rel(a.get(), c) < TOL
+
+
+def test_round_on_device(tsa):
+    """TensorTrain.round_dev / orthogonalize_dev == the host versions (reference tensor.py:446-484,
+    :559-572) as tensors; orthogonality and rank rules identical; ttsk_svd_small reconstructs."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(17)
+    A = rng.standard_normal((40, 40))
+    d = DevArray.from_host(A)
+    US, S, Vt = DevArray.empty((40, 40)), DevArray.empty((40,)), DevArray.empty((40, 40))
+    nat.call("ttsk_svd_small", ctypes.c_void_p(d.ptr), 40, 40, ctypes.c_void_p(US.ptr), ctypes.c_void_p(S.ptr),
+             ctypes.c_void_p(Vt.ptr), 0)
+    assert rel(US.get() @ Vt.get(), A) < 1e-12
+    assert rel(S.get(), np.linalg.svd(A, compute_uv=False)) < 1e-12
+    assert np.linalg.norm(Vt.get() @ Vt.get().T - np.eye(40)) < 1e-12
+    for shape, ranks, kw in [((9, 12, 7, 10), (5, 8, 6), dict(max_rank=4)),
+                             ((30, 40, 30, 20, 30), (20, 35, 35, 18), dict(max_rank=12)),
+                             ((30, 40, 30, 20, 30), (20, 35, 35, 18), dict(eps=0.05)),
+                             ((16, 16, 16), (8, 8), dict())]:
+        tt = tsa.TensorTrain(orc.random_tt(shape, ranks, rng))
+        o = tt.orthogonalize_dev()
+        assert rel(o.to_numpy(), tt.to_numpy()) < 1e-12
+        for C in o.cores[:-1]:
+            Q = C.get().reshape(-1, C.shape[2])
+            assert np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) < 1e-11
+        want = tt.round(**kw)
+        got = tt.round_dev(**kw)
+        assert got.rank == want.rank
+        assert rel(got.to_numpy(), want.to_numpy()) < 1e-10

@@ -16,10 +16,13 @@ namespace ttsk {
 // ---------------------------------------------------------------- Jacobi SVD pinv
 // W: mW x nW (mW >= nW) column-major in Wc (column j at Wc + j*mW), V: nW x nW column-major.
 // On exit P[i*ldp_i + k*ldp_k] = sum_{j kept} Wc_j[i] * V_j[k] / sigma_j^2.
+// With svd_US != nullptr the kernel returns the factors instead of the pseudo-inverse (input taken
+// untransposed, l >= r): US (l x r row-major) = U diag(S), S (r) descending, Vt (r x r row-major).
 __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restrict__ omega, int64_t l,
                                                            int64_t r, int transposed, double *Wc,
                                                            double *V, double rcond, double *P,
-                                                           int *rank_out)
+                                                           int *rank_out, double *svd_US = nullptr,
+                                                           double *svd_S = nullptr, double *svd_Vt = nullptr)
 {
     const int mW = (int)(transposed ? r : l), nW = (int)(transposed ? l : r);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
@@ -86,6 +89,31 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
         if (lane == 0) s_inv2[j] = a;  // sigma^2
     }
     __syncthreads();
+    if (svd_US) {
+        // order the columns by descending singular value (nW <= 1024, one thread)
+        __shared__ int s_ord[1024];
+        if (tid == 0) {
+            for (int j = 0; j < nW; ++j) s_ord[j] = j;
+            for (int a = 1; a < nW; ++a) {
+                const int key = s_ord[a];
+                const double kv = s_inv2[key];
+                int b = a - 1;
+                while (b >= 0 && s_inv2[s_ord[b]] < kv) { s_ord[b + 1] = s_ord[b]; --b; }
+                s_ord[b + 1] = key;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < mW * nW; t += blockDim.x) {
+            const int i = t / nW, k = t - i * nW;
+            svd_US[t] = Wc[(size_t)s_ord[k] * mW + i];
+        }
+        for (int t = tid; t < nW * nW; t += blockDim.x) {
+            const int k = t / nW, i = t - k * nW;
+            svd_Vt[t] = V[(size_t)s_ord[k] * nW + i];
+        }
+        for (int k = tid; k < nW; k += blockDim.x) svd_S[k] = sqrt(s_inv2[s_ord[k]]);
+        return;
+    }
     if (tid == 0) {
         double mx = 0;
         for (int j = 0; j < nW; ++j) mx = fmax(mx, s_inv2[j]);
@@ -457,6 +485,21 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     TTSK_HIP(e);
+    return TTSK_OK;
+}
+
+int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,
+                   int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_A && dev_US && dev_S && dev_Vt, "ttsk_svd_small: NULL argument");
+    TTSK_ARG(m >= n && n >= 1 && n <= 1024, "ttsk_svd_small: need m >= n, 1 <= n <= 1024, got (%lld, %lld)",
+             (long long)m, (long long)n);
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(m * n + n * n) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
+                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt);
+    TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
 

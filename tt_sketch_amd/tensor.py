@@ -399,9 +399,74 @@ class TensorTrain(Tensor):
     def norm(self) -> float:
         return float(np.linalg.norm(self.orthogonalize().cores[-1]))
 
+    # ---- device versions (the step after to_tt) -------------------------
+    def orthogonalize_dev(self) -> "TensorTrain":
+        """Left-orthogonalising QR sweep on the device: thin QR by ``ttsk_qr_thin`` (CholeskyQR2
+        with LAPACK's signs, Householder fallback), R recovered as Q^T M by the long-K kernel.
+        Same result as ``orthogonalize`` (reference tensor.py:559-572) up to rounding."""
+        import ctypes
+        from . import _native as nat
+        from .device import contract
+        cores = self.dev_cores()
+        out, carry = [], None
+        for k, C in enumerate(cores):
+            if carry is not None:
+                C = contract("ij,jkl->ikl", carry, C)
+            if k < self.ndim - 1:
+                r1, n, r2 = C.shape
+                if r1 * n < r2:                      # wide unfolding: nothing to orthogonalise against
+                    return self.orthogonalize()
+                M = C.contiguous().reshape(r1 * n, r2)
+                Q = M.copy()
+                nat.call("ttsk_qr_thin", ctypes.c_void_p(Q.ptr), r1 * n, r2, 0)
+                carry = contract("ai,aj->ij", Q, M)
+                out.append(Q.reshape(r1, n, r2))
+            else:
+                out.append(C.contiguous())
+        return TensorTrain(out)
+
+    def round_dev(self, eps: Optional[float] = None, max_rank: Optional[TTRank] = None,
+                  orthogonalized: bool = False) -> "TensorTrain":
+        """TT-SVD rounding on the device, the algorithm of ``round`` (reference tensor.py:446-484):
+        the SVD of each wide unfolding M (r x n r') goes through the thin QR of M^T and a Jacobi SVD
+        of the r x r factor (``ttsk_svd_small``).  Cores stay on the device; they equal ``round``'s
+        up to the sign gauge of the singular vectors (the represented tensor is the same)."""
+        import ctypes
+        from . import _native as nat
+        from .device import DevArray, contract
+        tt = self if orthogonalized else self.orthogonalize_dev()
+        eps = 0 if eps is None else eps
+        cap = process_tt_rank(tt.rank if max_rank is None else max_rank, tt.shape, trim=True)
+        cores = tt.dev_cores()
+        out, carry = [], None
+        for k in range(tt.ndim - 1, -1, -1):
+            C = cores[k]
+            if carry is not None:
+                C = contract("ijk,kl->ijl", C, carry)
+            if k == 0:
+                out.append(C)
+                continue
+            r1, n, r2 = C.shape
+            if n * r2 < r1:
+                return self.round(eps=eps, max_rank=max_rank, orthogonalized=orthogonalized)
+            Mt = C.reshape(r1, n * r2).T.contiguous()                # (n r2, r1), tall
+            Qc = Mt.copy()
+            nat.call("ttsk_qr_thin", ctypes.c_void_p(Qc.ptr), n * r2, r1, 0)
+            Rc = contract("ai,aj->ij", Qc, Mt)                       # (r1, r1) upper triangular
+            A = Rc.T.contiguous()                                    # M = Rc^T Qc^T
+            US, S, Vt = DevArray.empty((r1, r1)), DevArray.empty((r1,)), DevArray.empty((r1, r1))
+            nat.call("ttsk_svd_small", ctypes.c_void_p(A.ptr), r1, r1, ctypes.c_void_p(US.ptr),
+                     ctypes.c_void_p(S.ptr), ctypes.c_void_p(Vt.ptr), 0)
+            sv = S.get()
+            r = max(1, min(int(np.sum(sv > sv[0] * eps)), cap[k - 1]))
+            carry = US[:, :r]
+            out.append(contract("ab,cb->ac", Vt[:r], Qc).reshape(r, n, r2))
+        return TensorTrain(out[::-1])
+
     def round(self, eps: Optional[float] = None, max_rank: Optional[TTRank] = None,
               orthogonalized: bool = False) -> "TensorTrain":
-        """TT-SVD rounding (reference tensor.py:446-484); host LAPACK, off the sketch path."""
+        """TT-SVD rounding (reference tensor.py:446-484); host LAPACK (``round_dev`` is the device
+        version)."""
         tt = self if orthogonalized else self.orthogonalize()
         eps = 0 if eps is None else eps
         cap = process_tt_rank(tt.rank if max_rank is None else max_rank, tt.shape, trim=True)
