@@ -204,6 +204,10 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
  * one workgroup.  US (m, n) = U diag(S), S (n) descending, Vt (n, n); A = US Vt. */
 int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,
                    int stream);
+/* zero the strictly lower triangle of A (m, n) row-major: the triangular factor R = Q^T M of a thin
+ * QR recovered by a product is upper triangular only up to rounding; np.linalg.qr (tensor.py:568)
+ * returns exact zeros there, which is what keeps structurally zero singular values exactly zero. */
+int ttsk_triu(double *dev_A, int64_t m, int64_t n, int stream);
 /* thin QR of orth_step (sketch_dispatch.py:172, scipy.linalg.qr(mode="economic")):
  * A (m, n) row-major with m >= n is overwritten by Q (m, n); Householder with LAPACK's
  * sign convention.  R is not returned (the reference discards it). */

@@ -290,6 +290,71 @@ def sketch_fixture():
     print("sketch_cases.npz", len(out), "arrays,", len(meta), "cases")
 
 
+# ------------------------------------------------------------------ tt_gmres
+def gmres_fixture():
+    """Reference ``tt_sum_gmres`` with the deterministic roundings ("exact", "pairwise") on a small
+    preconditioned problem, plus one MPO product and both TTPrecond directions."""
+    from tt_sketch.tt_gmres import MPO, TTLinearMapSum, TTPrecond, tt_sum_gmres
+    rng = np.random.default_rng(77)
+    shape = (6, 5, 4, 5)
+    d = len(shape)
+    out = {"shape": np.array(shape)}
+
+    def mpo_cores(rank, scale):
+        rk = (1,) + (rank,) * (d - 1) + (1,)
+        cores = []
+        for k, n in enumerate(shape):
+            C = rng.standard_normal((rk[k], n, n, rk[k + 1]))
+            C = C + C.transpose(0, 2, 1, 3)
+            cores.append(C * (scale ** (1 / d)) / np.sqrt(C.size))
+        return cores
+
+    maps = [[2.0 ** (k == 0) * np.eye(n).reshape(1, n, n, 1) for k, n in enumerate(shape)],
+            mpo_cores(2, 0.4), mpo_cores(3, 0.3)]
+    for m, cores in enumerate(maps):
+        for k, C in enumerate(cores):
+            out[f"map{m}_core{k}"] = C
+    P = rng.standard_normal((shape[1], shape[1]))
+    P = P @ P.T / shape[1] + np.eye(shape[1])
+    out["precond"] = P
+    b = TensorTrain.random(shape, 2)
+    b.cores = [rng.standard_normal(C.shape) / np.sqrt(C.shape[0] * C.shape[1]) for C in b.cores]
+    for k, C in enumerate(b.cores):
+        out[f"b_core{k}"] = C
+
+    A = TTLinearMapSum([MPO([C.copy() for C in cores]) for cores in maps])
+    pre = TTPrecond(P, shape, mode=1)
+    out["mpo_apply"] = MPO(maps[2])(b).to_numpy()
+    out["precond_backward"] = pre.backward_call(b).to_numpy()
+    out["precond_forward"] = pre.forward_call(b).to_numpy()
+    for method in ("exact", "pairwise"):
+        for use_pre in (False, True):
+            x, hist = tt_sum_gmres(A, b, max_rank=6, precond=pre if use_pre else None, tolerance=1e-8,
+                                   maxiter=8, rounding_method=method, save_basis=True)
+            key = f"{method}_{int(use_pre)}"
+            out[key + "_x"] = x.to_numpy()
+            out[key + "_residual_norm"] = np.array(hist["residual_norm"])
+            out[key + "_w_norm"] = np.array(hist["w_norm"])
+            out[key + "_rank"] = np.array(hist["rank"])
+            out[key + "_H"] = hist["H_matrix"]
+            out[key + "_y"] = hist["y"]
+            print("gmres", key, hist["residual_norm"][-1], hist["rank"][-1])
+    # sketched roundings at a rank that represents every iterate exactly: the run is then independent
+    # of the random DRMs (to rounding) and comparable across implementations
+    for method in ("sketch", "orth_sketch"):
+        x, hist = tt_sum_gmres(A, b, max_rank=30, tolerance=1e-9, maxiter=25, rounding_method=method)
+        out[method + "_full_x"] = x.to_numpy()
+        out[method + "_full_residual_norm"] = np.array(hist["residual_norm"])
+        out[method + "_full_rank"] = np.array(hist["rank"])
+        print("gmres", method, hist["residual_norm"])
+    np.savez_compressed(os.path.join(HERE, "gmres_case.npz"), **out)
+
+
 if __name__ == "__main__":
-    sampler_fixture()
-    sketch_fixture()
+    which = sys.argv[1:] or ["sampler", "sketch", "gmres"]
+    if "sampler" in which:
+        sampler_fixture()
+    if "sketch" in which:
+        sketch_fixture()
+    if "gmres" in which:
+        gmres_fixture()

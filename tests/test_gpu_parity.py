@@ -523,10 +523,13 @@ def test_round_on_device(tsa):
     for shape, ranks, kw in [((9, 12, 7, 10), (5, 8, 6), dict(max_rank=4)),
                              ((30, 40, 30, 20, 30), (20, 35, 35, 18), dict(max_rank=12)),
                              ((30, 40, 30, 20, 30), (20, 35, 35, 18), dict(eps=0.05)),
-                             ((16, 16, 16), (8, 8), dict())]:
+                             ((16, 16, 16), (8, 8), dict()),
+                             ((3, 4, 3, 5), (9, 20, 11), dict(max_rank=5)),      # infeasible (wide / tall) ranks
+                             ((3, 4, 3, 5), (9, 20, 11), dict(eps=1e-3))]:
         tt = tsa.TensorTrain(orc.random_tt(shape, ranks, rng))
         o = tt.orthogonalize_dev()
         assert rel(o.to_numpy(), tt.to_numpy()) < 1e-12
+        assert o.resident() and tt.round_dev(**kw).resident()
         for C in o.cores[:-1]:
             Q = C.get().reshape(-1, C.shape[2])
             assert np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) < 1e-11
@@ -534,3 +537,96 @@ def test_round_on_device(tsa):
         got = tt.round_dev(**kw)
         assert got.rank == want.rank
         assert rel(got.to_numpy(), want.to_numpy()) < 1e-10
+
+
+# ------------------------------------------------------------------ TT-GMRES
+def _gmres_problem(tsa):
+    from tt_sketch_amd.tt_gmres import MPO, TTLinearMapSum, TTPrecond
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gmres_case.npz"))
+    shape = tuple(int(n) for n in z["shape"])
+    d = len(shape)
+    maps = [[z[f"map{m}_core{k}"] for k in range(d)] for m in range(3)]
+    b = tsa.TensorTrain([z[f"b_core{k}"] for k in range(d)])
+    A = TTLinearMapSum([MPO(list(cores)) for cores in maps])
+    return z, shape, maps, b, A, TTPrecond(z["precond"], shape, mode=1)
+
+
+def test_mpo_and_precond_on_device(tsa):
+    """MPO.__call__ / TTPrecond against the reference's outputs (tt_gmres.py:90-101, :137-168) and
+    the reference's own test_mpo_contract property."""
+    from tt_sketch_amd.tt_gmres import MPO
+    z, shape, maps, b, A, pre = _gmres_problem(tsa)
+    assert rel(MPO(maps[2])(b).to_numpy(), z["mpo_apply"]) < 1e-13
+    assert rel(pre.backward_call(b).to_numpy(), z["precond_backward"]) < 1e-12
+    assert rel(pre.forward_call(b).to_numpy(), z["precond_forward"]) < 1e-13
+    np.random.seed(5)
+    mpo = MPO.random(3, (4, 5, 6), (4, 5, 6))
+    dense = mpo.to_numpy()
+    assert np.linalg.norm(dense - dense.transpose(1, 0, 3, 2, 5, 4)) < 1e-12
+    tt = tsa.TensorTrain.random((4, 5, 6), 2, seed=1)
+    assert np.linalg.norm(np.einsum("ijk,iajbkc", tt.to_numpy(), dense) - mpo(tt).to_numpy()) < 1e-12
+    assert rel(mpo.T(tt).to_numpy(), np.einsum("ijk,aibjck", tt.to_numpy(), dense)) < 1e-12
+    with pytest.raises(ValueError):
+        mpo(tsa.TensorTrain.random((4, 5, 7), 2, seed=1))
+
+
+def test_resident_tt_arithmetic(tsa):
+    rng = np.random.default_rng(3)
+    a = tsa.TensorTrain(orc.random_tt((5, 6, 7, 4), (3, 4, 2), rng))
+    b = tsa.TensorTrain(orc.random_tt((5, 6, 7, 4), (2, 5, 3), rng))
+    ad, bd = a.to_device(), b.to_device()
+    assert ad.resident() and not a.resident()
+    assert rel(ad.add(bd).to_numpy(), a.to_numpy() + b.to_numpy()) < 1e-14
+    assert ad.add(bd).rank == a.add(b).rank
+    assert abs(ad.dot(bd) - a.dot(b)) < 1e-13 * a.norm() * b.norm()
+    assert abs(ad.norm() - a.norm()) < 1e-13 * a.norm()
+    assert rel((ad * -2.5).to_numpy(), -2.5 * a.to_numpy()) < 1e-15
+    assert rel((ad - bd * 0.5).to_numpy(), a.to_numpy() - 0.5 * b.to_numpy()) < 1e-14
+    assert abs(ad.error(bd) - a.error(b)) < 1e-12 * a.norm()
+
+
+@pytest.mark.parametrize("method", ["exact", "pairwise"])
+@pytest.mark.parametrize("use_pre", [0, 1])
+def test_gmres_matches_reference_run(tsa, method, use_pre):
+    """tt_sum_gmres with the deterministic roundings reproduces the reference's run (golden) and
+    the oracle's: residual history, ranks, Hessenberg matrix and solution."""
+    from oracle import tt_gmres_oracle as g
+    from tt_sketch_amd.tt_gmres import tt_sum_gmres
+    z, shape, maps, b, A, pre = _gmres_problem(tsa)
+    x, hist = tt_sum_gmres(A, b, max_rank=6, precond=pre if use_pre else None, tolerance=1e-8, maxiter=8,
+                           rounding_method=method, save_basis=True)
+    key = f"{method}_{use_pre}"
+    assert x.resident()
+    assert np.allclose(hist["residual_norm"], z[key + "_residual_norm"], rtol=1e-6)
+    assert np.array_equal(np.array(hist["rank"]), z[key + "_rank"])
+    assert np.allclose(hist["H_matrix"], z[key + "_H"], rtol=1e-5, atol=1e-8)
+    assert rel(x.to_numpy(), z[key + "_x"]) < 1e-7
+    xo, ho = g.gmres(maps, [z[f"b_core{k}"] for k in range(len(shape))], 6,
+                     precond=(z["precond"], 1) if use_pre else None, tolerance=1e-8, maxiter=8, method=method)
+    assert rel(x.to_numpy(), orc.tt_to_numpy(xo)) < 1e-7
+    for k in ("w_norm", "delta", "step_time", "step_time_with_res_norm", "final_round_time", "total_time"):
+        assert k in hist
+
+
+@pytest.mark.parametrize("method", ["sketch", "orth_sketch"])
+def test_gmres_sketched_rounding(tsa, method):
+    """Sketched rounding at a rank that represents every iterate exactly: the run does not depend on
+    the random DRMs (no stream parity) and must reproduce the reference's -- including its
+    stopping rule on the squared residual (tt_gmres.py:407-416) -- and approach the dense solution."""
+    from tt_sketch_amd.tt_gmres import tt_sum_gmres
+    z, shape, maps, b, A, pre = _gmres_problem(tsa)
+    x, hist = tt_sum_gmres(A, b, max_rank=30, tolerance=1e-9, maxiter=25, rounding_method=method)
+    assert np.allclose(hist["residual_norm"], z[method + "_full_residual_norm"], rtol=1e-4)
+    assert np.array_equal(np.array(hist["rank"]), z[method + "_full_rank"])
+    assert rel(x.to_numpy(), z[method + "_full_x"]) < 1e-7
+    N = int(np.prod(shape))
+    dense = sum(np.einsum("aibjckdl->abcdijkl", m.to_numpy()).reshape(N, N) for m in A.linear_maps)
+    x_true = np.linalg.solve(dense.T, b.to_numpy().ravel()).reshape(shape)
+    assert rel(x.to_numpy(), x_true) < 10 * hist["residual_norm"][-1]
+    # truncating sketch: still converges, ranks capped
+    x, hist = tt_sum_gmres(A, b, max_rank=10, tolerance=1e-6, maxiter=6, rounding_method=method)
+    assert hist["residual_norm"][-1] < 2e-2 and max(x.rank) <= 10
+    with pytest.raises(ValueError):
+        tt_sum_gmres(A, tsa.TensorTrain.random((6, 5, 4, 4), 2, seed=0), max_rank=4)
+    with pytest.raises(ValueError):
+        tt_sum_gmres(A, b, max_rank=4, rounding_method="nope", maxiter=1)

@@ -108,3 +108,34 @@ def test_sketch_golden(name):
             # same LAPACK calls -> same gauge; compare directly, loosely
             for g, w in zip(Psis, wantP):
                 assert rel(g, w) < 1e-8
+
+
+# ------------------------------------------------------------------ TT-GMRES
+def _gmres_case():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gmres_case.npz"))
+    d = len(z["shape"])
+    maps = [[z[f"map{m}_core{k}"] for k in range(d)] for m in range(3)]
+    b = [z[f"b_core{k}"] for k in range(d)]
+    return z, maps, b
+
+
+def test_gmres_oracle_blocks_match_reference():
+    from oracle import tt_gmres_oracle as g
+    z, maps, b = _gmres_case()
+    assert rel(orc.tt_to_numpy(g.mpo_apply(maps[2], b)), z["mpo_apply"]) < 1e-13
+    assert rel(orc.tt_to_numpy(g.precond_apply(z["precond"], b, 1, True)), z["precond_backward"]) < 1e-13
+    assert rel(orc.tt_to_numpy(g.precond_apply(z["precond"], b, 1, False)), z["precond_forward"]) < 1e-13
+
+
+@pytest.mark.parametrize("method", ["exact", "pairwise"])
+@pytest.mark.parametrize("use_pre", [0, 1])
+def test_gmres_oracle_matches_reference_run(method, use_pre):
+    from oracle import tt_gmres_oracle as g
+    z, maps, b = _gmres_case()
+    x, hist = g.gmres(maps, b, 6, precond=(z["precond"], 1) if use_pre else None, tolerance=1e-8,
+                      maxiter=8, method=method)
+    key = f"{method}_{use_pre}"
+    assert np.allclose(hist["residual_norm"], z[key + "_residual_norm"], rtol=1e-7)
+    assert np.array_equal(np.array(hist["rank"]), z[key + "_rank"])
+    assert np.allclose(hist["H_matrix"], z[key + "_H"], rtol=1e-6, atol=1e-9)
+    assert rel(orc.tt_to_numpy(x), z[key + "_x"]) < 1e-8

@@ -245,6 +245,13 @@ __global__ void eye_kernel(double *Q, int64_t m, int64_t n)
         Q[t] = (t / n == t % n) ? 1.0 : 0.0;
 }
 
+__global__ void triu_kernel(double *A, int64_t m, int64_t n)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m * n;
+         t += (int64_t)gridDim.x * blockDim.x)
+        if (t % n < t / n) A[t] = 0.0;
+}
+
 }  // namespace ttsk
 
 namespace ttsk {
@@ -499,6 +506,16 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
     if (!ws) return TTSK_ERR_HIP;
     hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
                        (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_triu(double *A, int64_t m, int64_t n, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(A && m >= 1 && n >= 1, "ttsk_triu: bad argument");
+    const int64_t blocks = cdiv(m * n, 256);
+    hipLaunchKernelGGL(triu_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, A, m, n);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

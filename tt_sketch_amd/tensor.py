@@ -24,7 +24,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import numpy.typing as npt
 
-from .device import DevArray, as_dev
+from .device import DevArray, as_dev, axpby, contract, copy_into
 from .utils import ArrayList, TTRank, process_tt_rank, random_normal
 
 
@@ -397,7 +397,18 @@ class TensorTrain(Tensor):
         return TensorTrain(out)
 
     def norm(self) -> float:
+        if self.resident():
+            return float(np.linalg.norm(self.orthogonalize_dev().cores[-1].get()))
         return float(np.linalg.norm(self.orthogonalize().cores[-1]))
+
+    def resident(self) -> bool:
+        """True if the cores live in HBM only (as ``to_tt`` / ``round_dev`` / an MPO product leave
+        them); arithmetic on such a train stays on the device."""
+        return all(isinstance(c, DevArray) for c in self.cores)
+
+    def to_device(self) -> "TensorTrain":
+        """The same train with device-resident cores (uploads host cores once)."""
+        return self if self.resident() else TensorTrain(list(self.dev_cores()))
 
     # ---- device versions (SURVEY.md 8f rank 1: the step after to_tt) -------------------------
     def orthogonalize_dev(self) -> "TensorTrain":
@@ -414,13 +425,15 @@ class TensorTrain(Tensor):
                 C = contract("ij,jkl->ikl", carry, C)
             if k < self.ndim - 1:
                 r1, n, r2 = C.shape
-                if r1 * n < r2:                      # wide unfolding: nothing to orthogonalise against
-                    return self.orthogonalize()
                 M = C.contiguous().reshape(r1 * n, r2)
-                Q = M.copy()
-                nat.call("ttsk_qr_thin", ctypes.c_void_p(Q.ptr), r1 * n, r2, 0)
+                m = r1 * n
+                # wide unfolding (m < r2): Q (m x m) from the leading square block, R = Q^T M is m x r2
+                Q = M.copy() if m >= r2 else M[:, :m].contiguous()
+                q = min(m, r2)
+                nat.call("ttsk_qr_thin", ctypes.c_void_p(Q.ptr), m, q, 0)
                 carry = contract("ai,aj->ij", Q, M)
-                out.append(Q.reshape(r1, n, r2))
+                nat.call("ttsk_triu", ctypes.c_void_p(carry.ptr), q, r2, 0)
+                out.append(Q.reshape(r1, n, q))
             else:
                 out.append(C.contiguous())
         return TensorTrain(out)
@@ -433,7 +446,6 @@ class TensorTrain(Tensor):
         up to the sign gauge of the singular vectors (the represented tensor is the same)."""
         import ctypes
         from . import _native as nat
-        from .device import DevArray, contract
         tt = self if orthogonalized else self.orthogonalize_dev()
         eps = 0 if eps is None else eps
         cap = process_tt_rank(tt.rank if max_rank is None else max_rank, tt.shape, trim=True)
@@ -447,20 +459,38 @@ class TensorTrain(Tensor):
                 out.append(C)
                 continue
             r1, n, r2 = C.shape
-            if n * r2 < r1:
+            C = C.contiguous()
+            k2 = n * r2
+            if k2 < r1:
+                # tall unfolding M (r1 x k2): one-sided Jacobi over the ROWS of M (columns of M^T padded
+                # to r1 x r1), so rows that are exactly zero -- a zero summand -- give exactly zero
+                # singular values as they do in LAPACK.  M^T = US Vt  =>  M = Vt^T diag(S) (US/S)^T.
+                A = DevArray.zeros((r1, r1))
+                copy_into(A[:k2], C.reshape(r1, k2).T)
+                Qc = None
+            else:
+                Mt = C.reshape(r1, k2).T.contiguous()                # (n r2, r1), tall
+                Qc = Mt.copy()
+                nat.call("ttsk_qr_thin", ctypes.c_void_p(Qc.ptr), k2, r1, 0)
+                Rc = contract("ai,aj->ij", Qc, Mt)                   # (r1, r1) upper triangular
+                nat.call("ttsk_triu", ctypes.c_void_p(Rc.ptr), r1, r1, 0)
+                A = Rc.T.contiguous()                                # M = Rc^T Qc^T
+            if r1 > 1024:
                 return self.round(eps=eps, max_rank=max_rank, orthogonalized=orthogonalized)
-            Mt = C.reshape(r1, n * r2).T.contiguous()                # (n r2, r1), tall
-            Qc = Mt.copy()
-            nat.call("ttsk_qr_thin", ctypes.c_void_p(Qc.ptr), n * r2, r1, 0)
-            Rc = contract("ai,aj->ij", Qc, Mt)                       # (r1, r1) upper triangular
-            A = Rc.T.contiguous()                                    # M = Rc^T Qc^T
             US, S, Vt = DevArray.empty((r1, r1)), DevArray.empty((r1,)), DevArray.empty((r1, r1))
             nat.call("ttsk_svd_small", ctypes.c_void_p(A.ptr), r1, r1, ctypes.c_void_p(US.ptr),
                      ctypes.c_void_p(S.ptr), ctypes.c_void_p(Vt.ptr), 0)
             sv = S.get()
-            r = max(1, min(int(np.sum(sv > sv[0] * eps)), cap[k - 1]))
-            carry = US[:, :r]
-            out.append(contract("ab,cb->ac", Vt[:r], Qc).reshape(r, n, r2))
+            r = max(1, min(int(np.sum(sv > sv[0] * eps)), cap[k - 1], k2))
+            if Qc is None:
+                eye = DevArray.from_host(np.eye(r))
+                inv = np.divide(1.0, sv[:r], out=np.zeros(r), where=sv[:r] > 0)
+                carry = contract("ka,kb->ab", Vt[:r], eye, k_scale=S[:r].contiguous())
+                V = contract("ka,ck->ac", eye, US[:k2, :r], k_scale=DevArray.from_host(inv))
+            else:
+                carry = US[:, :r]
+                V = contract("ab,cb->ac", Vt[:r], Qc)
+            out.append(V.reshape(r, n, r2))
         return TensorTrain(out[::-1])
 
     def round(self, eps: Optional[float] = None, max_rank: Optional[TTRank] = None,
@@ -498,6 +528,10 @@ class TensorTrain(Tensor):
         return vals[::-1]
 
     def __mul__(self, other: float) -> "TensorTrain":
+        if self.resident():
+            last = self.cores[-1].copy()
+            axpby(last, last, float(other), 0.0)
+            return TensorTrain(list(self.cores[:-1]) + [last])
         cores = [np.array(_host(c)) for c in self.cores]
         cores[-1] = cores[-1] * other
         return TensorTrain(cores)
@@ -510,6 +544,18 @@ class TensorTrain(Tensor):
 
     def add(self, other: "TensorTrain") -> "TensorTrain":
         """Direct-sum addition of two TTs (reference tensor.py:503-525)."""
+        if self.resident() and other.resident():
+            out, d = [], self.ndim
+            for k, (a, b) in enumerate(zip(self.cores, other.cores)):
+                ra1, n, ra2 = a.shape
+                rb1, _, rb2 = b.shape
+                r1 = 1 if k == 0 else ra1 + rb1
+                r2 = 1 if k == d - 1 else ra2 + rb2
+                blk = DevArray.zeros((r1, n, r2))
+                copy_into(blk[:ra1, :, :ra2], a)
+                copy_into(blk[r1 - rb1:, :, r2 - rb2:], b)
+                out.append(blk)
+            return TensorTrain(out)
         A = [_host(c) for c in self.cores]
         B = [_host(c) for c in other.cores]
         out = [np.concatenate((A[0], B[0]), axis=2)]
@@ -522,6 +568,13 @@ class TensorTrain(Tensor):
         return TensorTrain(out)
 
     def dot(self, other, reverse=False) -> float:
+        if isinstance(other, TensorTrain) and self.resident() and other.resident():
+            acc = None
+            for a, b in zip(self.cores, other.cores):
+                t = a.reshape(a.shape[1], a.shape[2]) if acc is None else contract("ij,ika->jka", acc, a)
+                b = b.reshape(b.shape[1], b.shape[2]) if acc is None else b
+                acc = contract("ka,kb->ab", t, b) if acc is None else contract("jka,jkb->ab", t, b)
+            return float(acc.get().sum())
         if isinstance(other, TensorTrain):
             acc = np.ones((1, 1))
             for a, b in zip(self.cores, other.cores):
