@@ -22,9 +22,15 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
                                                            int64_t r, int transposed, double *Wc,
                                                            double *V, double rcond, double *P,
                                                            int *rank_out, double *svd_US = nullptr,
-                                                           double *svd_S = nullptr, double *svd_Vt = nullptr)
+                                                           double *svd_S = nullptr, double *svd_Vt = nullptr,
+                                                           int lds_mode = 0)
 {
     const int mW = (int)(transposed ? r : l), nW = (int)(transposed ? l : r);
+    // lds_mode 1: W lives in LDS, 2: W and V (the global scratch is then unused) -- a rotation is two
+    // dependent passes over a column pair, so the latency of where the columns live is the run time
+    extern __shared__ double jac_lds[];
+    if (lds_mode >= 1) Wc = jac_lds;
+    if (lds_mode >= 2) V = jac_lds + (size_t)mW * nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     __shared__ int s_rot;
     __shared__ double s_smax;
@@ -452,6 +458,30 @@ static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_
 
 using namespace ttsk;
 
+// where the Jacobi working set lives: 2 = W and V in LDS, 1 = W only, 0 = global scratch
+static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
+{
+    static const int off = getenv("TTSK_JACOBI_GLOBAL") ? 1 : 0;
+    static int attr_done = 0;
+    const size_t cap = 128 * 1024;                  // + 12.3 KB static in the kernel, 160 KB per CU
+    const size_t w = (size_t)mW * nW * 8, v = (size_t)nW * nW * 8;
+    int mode = 0;
+    *bytes = 0;
+    if (!off) {
+        if (w + v <= cap) { mode = 2; *bytes = w + v; }
+        else if (w <= cap) { mode = 1; *bytes = w; }
+    }
+    if (mode && !attr_done) {
+        if (hipFuncSetAttribute((const void *)jacobi_pinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)cap) != hipSuccess) {
+            set_error("jacobi: cannot raise the dynamic LDS limit");
+            return -1;
+        }
+        attr_done = 1;
+    }
+    return mode;
+}
+
 extern "C" {
 
 int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
@@ -484,8 +514,12 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     double *ws = (double *)scratch(stream, SCRATCH_MISC, ws_elems * 8);
     if (!ws) return TTSK_ERR_HIP;
     int *drank = (int *)(ws + mW * nW + nW * nW);
-    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_omega, l, r, transposed, ws,
-                       ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr);
+    size_t jl = 0;
+    const int jm = jacobi_lds_mode(mW, nW, &jl);
+    if (jm < 0) return TTSK_ERR_HIP;
+    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), jl, st, dev_omega, l, r, transposed, ws,
+                       ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr, (double *)nullptr,
+                       (double *)nullptr, (double *)nullptr, jm);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && host_rank) {
         e = hipMemcpyAsync(host_rank, drank, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -504,8 +538,11 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
              (long long)m, (long long)n);
     double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(m * n + n * n) * 8);
     if (!ws) return TTSK_ERR_HIP;
-    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), 0, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
-                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt);
+    size_t jl = 0;
+    const int jm = jacobi_lds_mode(m, n, &jl);
+    if (jm < 0) return TTSK_ERR_HIP;
+    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), jl, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
+                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt, jm);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

@@ -398,7 +398,10 @@ class TensorTrain(Tensor):
 
     def norm(self) -> float:
         if self.resident():
-            return float(np.linalg.norm(self.orthogonalize_dev().cores[-1].get()))
+            # Gram chain <x, x> on the device (2 d small products) instead of the QR sweep of the
+            # reference (tensor.py:442-444): every partial Gram matrix is positive semi-definite, so
+            # the relative error stays at a few ulp of ||x||^2 -- and there is no QR per norm.
+            return float(np.sqrt(max(self.dot(self), 0.0)))
         return float(np.linalg.norm(self.orthogonalize().cores[-1]))
 
     def resident(self) -> bool:
