@@ -234,7 +234,7 @@ def main():
         elapsed = float(t[0])
 
     # latency of ONE sketch issued alone (batch 1, nothing else in flight), for reference
-    single_ms = None
+    single_ms, api_ms = None, None
     if world == 1:
         one = (ctypes.c_void_p * plan.d)(*[ptrs[i] for i in range(plan.d)])
         for _ in range(3):
@@ -245,6 +245,21 @@ def main():
             plan.run(one, out)
         nat.call("ttsk_sync", -1)
         single_ms = 1e3 * (time.perf_counter() - t1) / 20
+        # T_total of SURVEY 8d = the reference's own timed region (scripts/experiment_base.py:102-113):
+        # stream_sketch() through the Python API incl. DRM sampling, and with to_tt() on top
+        import tt_sketch_amd as tsa
+        api_ms = {}
+        for name, fn in (("stream_sketch", lambda: tsa.stream_sketch(tt, left_rank=L_RANK, right_rank=R_RANK)),
+                         ("stream_sketch_to_tt", lambda: tsa.stream_sketch(tt, left_rank=L_RANK, right_rank=R_RANK).to_tt())):
+            best = float("inf")
+            for it in range(8):
+                nat.call("ttsk_sync", -1)
+                t1 = time.perf_counter()
+                fn()
+                nat.call("ttsk_sync", -1)
+                if it >= 2:
+                    best = min(best, 1e3 * (time.perf_counter() - t1))
+            api_ms[name] = best
         run_on(0)                      # restore the batched result checked below
         nat.call("ttsk_sync", -1)
 
@@ -322,7 +337,7 @@ def main():
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
                                   tts_per_step=B, steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
-                                  sketch_bytes=plan.size * 8),
+                                  t_total_ms_incl_drm_sampling=api_ms, sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
         print(json.dumps(result))
     if dist is not None:
