@@ -75,16 +75,16 @@ __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, uint32_t voff, dou
     __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<v2i_t *>(&v), r, (int)voff, 0, 0);
 }
 
-template <int NPT, int NT, bool SH, int D, int RB, bool BIG>
+template <int NPT, int NT, bool SH, int D, int RB, bool BIG, int STR>
 __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const double *Wl, const int v, const int tile0,
                                                    const int tshared);
 
-template <int NPT, int NT, bool SH, int D, int RB>
+template <int NPT, int NT, bool SH, int D, int RB, int STR = 0>
 __device__ __forceinline__ void skinny_s_wave(const SkinnyS &a, const double *Wl, const int v, const int tile0,
                                               const int tshared)
 {
-    if (a.big) skinny_s_wave_impl<NPT, NT, SH, D, RB, true>(a, Wl, v, tile0, tshared);
-    else skinny_s_wave_impl<NPT, NT, SH, D, RB, false>(a, Wl, v, tile0, tshared);
+    if (a.big) skinny_s_wave_impl<NPT, NT, SH, D, RB, true, STR>(a, Wl, v, tile0, tshared);
+    else skinny_s_wave_impl<NPT, NT, SH, D, RB, false, STR>(a, Wl, v, tile0, tshared);
 }
 
 // Stage W once per workgroup: Wl[k][m], zero beyond (K, P).  All loads of a thread are issued
@@ -134,7 +134,13 @@ __device__ __forceinline__ void skinny_s_stage(const SkinnyS &a, double *Wl)
 // BIG: operands or outputs beyond the reach of one buffer descriptor + 32-bit offset (dense
 // unfoldings); see the comment at `Sp` below.  Two variants because rebuilding a descriptor per load
 // costs the rank-100 chain shapes 4-9 %.
-template <int NPT, int NT, bool SH, int D, int RB, bool BIG>
+// STR > 0: the wave's last tile is W's partial tile with at most 4 STR valid columns (P mod 16 <= 8);
+// it is computed as STR strips of 4 by v_mfma_f64_4x4x4_4b -- the strip's 4 x 4 block of W against the
+// four 4-row blocks of the streamed register, which is that instruction's natural operand layout --
+// instead of one 16x16x4 of which 3/4 or 1/2 would be padding (100 = 6 x 16 + 4: the chain products
+// are bounded by the matrix pipe, so the padding was 1/7 of GEMM1's run time).  Strip s lands in
+// register s of the tile's accumulator, exactly where the 16x16x4 form keeps rows 4 s .. 4 s + 3.
+template <int NPT, int NT, bool SH, int D, int RB, bool BIG, int STR>
 __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const double *Wl, const int v, const int tile0,
                                                    const int tshared)
 {
@@ -207,6 +213,7 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
 
     const double *wl_lane = Wl + kq * LDW + x16 + 16 * tile0;
     const int soffS = 16 * (sh_on ? tshared : 0) - 16 * tile0;
+    const int soff4 = x16 & ~3;                   // strip operand: column 4 q + (x16 & 3) of the partial tile
 
     v4d accA[NTC], accB;      // [t]: the four 4x4x4 accumulators of a tile, or the 4 result registers of 16x16x4
 #pragma unroll
@@ -246,9 +253,12 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
             for (int d = 0; d < D; ++d) {
                 const int kb = it * D + d;
                 const double *wk = wl_lane + kb * 4 * LDW;
-                double af[NTC], as = 0.0;
+                double af[NTC], as = 0.0, sf[STR ? STR : 1];
+                constexpr int NFULL = STR ? NT - 1 : NT;
 #pragma unroll
-                for (int p = 0; p < NT; ++p) af[p] = wk[16 * p];
+                for (int p = 0; p < NFULL; ++p) af[p] = wk[16 * p];
+#pragma unroll
+                for (int q = 0; q < STR; ++q) sf[q] = wk[16 * (NT - 1) + 4 * q - soff4];
                 if (SH) as = wk[soffS];
                 double rA[4], rB[4];
                 const double sA = NT ? ringA[d] : 0.0, sB = SH ? ringB[d] : 0.0;
@@ -262,7 +272,9 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
                 }
                 if (TTSK_S_M16) {
 #pragma unroll
-                    for (int p = 0; p < NT; ++p) accA[p] = mfma16(af[p], sA, accA[p]);
+                    for (int p = 0; p < NFULL; ++p) accA[p] = mfma16(af[p], sA, accA[p]);
+#pragma unroll
+                    for (int q = 0; q < STR; ++q) accA[NT - 1][q] = mfma4(sf[q], sA, accA[NT - 1][q]);
                     if (SH) accB = mfma16(as, sB, accB);
                 } else {
 #pragma unroll
@@ -369,9 +381,10 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
 //         loaded twice.  The vector memory pipe (one tag lookup per touched line, 16 lines per
 //         k-fast load) is what saturates in these kernels, so this is the mode of choice whenever
 //         the group count still fills the CUs.
-template <int NPT, int MODE, int D>
+template <int NPT, int MODE, int D, int STR = 0>
 __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
 {
+    static_assert(TTSK_S_M16 || STR == 0, "strips need the 16x16x4 accumulator layout");
     extern __shared__ double Wl[];
     const int tid = threadIdx.x;
     SK_STAMP(0);
@@ -379,11 +392,12 @@ __global__ __launch_bounds__(512) void skinny_s_kernel(SkinnyS a)
     const int w = tid >> 6, v = w & 3;
     constexpr int H0 = (NPT + 1) / 2, H1 = NPT / 2;
     if constexpr (MODE == 2) {
-        skinny_s_wave<NPT, NPT, false, D, 8>(a, Wl, w, 0, 0);
+        skinny_s_wave<NPT, NPT, false, D, 8, STR>(a, Wl, w, 0, 0);
     } else {
         constexpr bool SH = MODE == 1;
-        if (w < 4) skinny_s_wave<NPT, H0, SH, D, SH ? 5 : 4>(a, Wl, v, 0, w);
-        else       skinny_s_wave<NPT, H1, SH, D, SH ? 5 : 4>(a, Wl, v, H0, w);
+        // the partial tile is the last one: it belongs to the upper waves (to the lower ones if NPT = 1)
+        if (w < 4) skinny_s_wave<NPT, H0, SH, D, SH ? 5 : 4, H1 == 0 ? STR : 0>(a, Wl, v, 0, w);
+        else       skinny_s_wave<NPT, H1, SH, D, SH ? 5 : 4, H1 == 0 ? 0 : STR>(a, Wl, v, H0, w);
     }
 }
 

@@ -4,10 +4,11 @@
 
 namespace ttsk {
 
-template <int D>
+template <int D, int STR>
 int launch_skinny_s_depth(const SkinnyS &a, int npt, int spt, size_t lds_bytes, int grid, hipStream_t st);
-extern template int launch_skinny_s_depth<4>(const SkinnyS &, int, int, size_t, int, hipStream_t);
-extern template int launch_skinny_s_depth<5>(const SkinnyS &, int, int, size_t, int, hipStream_t);
+#define TTSK_S_EXT(D, STR) extern template int launch_skinny_s_depth<D, STR>(const SkinnyS &, int, int, size_t, int, hipStream_t)
+TTSK_S_EXT(4, 0); TTSK_S_EXT(4, 1); TTSK_S_EXT(4, 2); TTSK_S_EXT(5, 0); TTSK_S_EXT(5, 1); TTSK_S_EXT(5, 2);
+#undef TTSK_S_EXT
 
 int launch_skinny_r_0(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
 int launch_skinny_r_1(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
@@ -101,9 +102,17 @@ static int run_s(SkinnyS a, hipStream_t st, int *prof, double flops)
     const size_t lds = (size_t)cdiv(kb, dring) * dring * 4 * ldw * 8;
     a.wpp = (int)(groups < cus ? groups : cus);
     const int grid = a.wpp * a.nb;
-    if (prof) prof_open(st, flops, 3, npt * 10 + spt, false, dring == 4);
-    if (dring == 4) return launch_skinny_s_depth<4>(a, npt, spt, lds, grid, st);
-    return launch_skinny_s_depth<5>(a, npt, spt, lds, grid, st);
+    // partial last tile of W with <= 8 valid columns: 4-wide strips instead of a padded 16x16x4 tile
+    static int strips_on = [] { const char *e = getenv("TTSK_S_STRIPS"); return e ? atoi(e) : 1; }();
+    const int rem = (int)(a.P % 16);
+    const int str = (strips_on && rem > 0 && rem <= 8) ? (rem + 3) / 4 : 0;
+    if (prof) prof_open(st, flops, 3, str * 1000 + npt * 100 + spt, str > 0, dring == 4);
+#define TTSK_S_GO(D) (str == 2 ? launch_skinny_s_depth<D, 2>(a, npt, spt, lds, grid, st) \
+                      : str == 1 ? launch_skinny_s_depth<D, 1>(a, npt, spt, lds, grid, st) \
+                                 : launch_skinny_s_depth<D, 0>(a, npt, spt, lds, grid, st))
+    if (dring == 4) return TTSK_S_GO(4);
+    return TTSK_S_GO(5);
+#undef TTSK_S_GO
 }
 
 // long-K: one side <= 128, the other <= 128 or cut into row tiles of 128; both operands contiguous
@@ -185,10 +194,10 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     r.slab = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nslab * nsub * r.M * r.N * 8 + 64);
     if (!r.slab) return TTSK_ERR_HIP;
     const bool prof = prof_on();
-    if (prof) prof_open(st, 2.0 * nb * (double)d.M * (double)d.N * (double)K, 4, nmt * 10 + nnt, false, false);
     int rc;
     // (a chunk -> XCD mapping that makes all problems of a batch fetch the shared operand into one L2
     // halved the L2-fabric traffic of the batched GEMM2 but not its time)
+    if (prof) prof_open(st, 2.0 * nb * (double)d.M * (double)d.N * (double)K, 4, nmt * 10 + nnt, false, false);
     if (nmt <= 4) rc = launch_skinny_r_0(r, nmt, nnt, (int)nslab, st);
     else if (nmt <= 6) rc = launch_skinny_r_1(r, nmt, nnt, (int)nslab, st);
     else if (nmt == 7) rc = launch_skinny_r_2(r, nmt, nnt, (int)nslab, st);

@@ -1,0 +1,4 @@
+#include "skinny_inst.h"
+namespace ttsk {
+template int launch_skinny_s_depth<4, 2>(const SkinnyS &, int, int, size_t, int, hipStream_t);
+}

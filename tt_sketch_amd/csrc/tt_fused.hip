@@ -28,8 +28,9 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     if (flops < g_kname_flops[g_cls]) family = -1;
     else g_kname_flops[g_cls] = flops;
     if (family < 0) {
-    } else if (family == 3)        // streamed x small: tiles = 10 * column tiles of the small operand + mode
-        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %d, %d>", tiles / 10, tiles % 10, bk ? 4 : 5);
+    } else if (family == 3)        // streamed x small: tiles = 10 * column tiles of the small operand + mode, ak = strips > 0
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_s_kernel<%d, %d, %d, %d>",
+                 tiles / 100 % 10, tiles % 10, bk ? 4 : 5, tiles / 1000);
     else if (family == 5)
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "small_gemm_kernel");
     else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
