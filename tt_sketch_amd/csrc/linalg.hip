@@ -281,58 +281,90 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
     double *A = sm;
-    __shared__ int bad;
-    __shared__ double rmin, rmax;
+    double *xd = sm + n * ld;
     for (int e = tid; e < n * n; e += 256) A[(e / n) * ld + e % n] = G[e];
-    if (tid == 0) { bad = 0; rmin = 1e300; rmax = 0.0; }
     __syncthreads();
+    // Unscaled right-looking recurrence, ONE barrier per column: row j keeps r_j R[j][:] (r_j^2 = pivot) until
+    // the end, the trailing update divides by the pivot instead; every thread reads the pivot itself.  (Pivot
+    // square root by one thread + scaling of row j + update were three barriers and a serial stretch per
+    // column: 75 of the kernel's 118 us at n = 50.)
+    int bad = 0;
+    double rmin = 1e300, rmax = 0.0;
+    const int ti = tid >> 4, tc = tid & 15;
     for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            const double p = A[j * ld + j];
-            if (!(p > 0.0)) { bad = 1; A[j * ld + j] = 1.0; }
-            else {
-                const double r = sqrt(p);
-                A[j * ld + j] = r;
-                rmin = r < rmin ? r : rmin;
-                rmax = r > rmax ? r : rmax;
-            }
-        }
-        __syncthreads();
-        const double rinv = 1.0 / A[j * ld + j];
-        for (int c = j + 1 + tid; c < n; c += 256) A[j * ld + c] *= rinv;
-        __syncthreads();
-        // trailing update of the upper triangle: A[i][c] -= R[j][i] R[j][c], j < i <= c
-        const int w = n - j - 1;
-        for (int e = tid; e < w * w; e += 256) {
-            const int i = j + 1 + e / w, c = j + 1 + e % w;
-            if (c >= i) A[i * ld + c] -= A[j * ld + i] * A[j * ld + c];
+        double piv = A[j * ld + j];
+        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+        const double r = sqrt(piv), pinv = 1.0 / piv;
+        rmin = r < rmin ? r : rmin;
+        rmax = r > rmax ? r : rmax;
+        const double *rj = A + j * ld;
+        for (int i = j + 1 + ti; i < n; i += 16) {
+            const double f = rj[i] * pinv;
+            for (int c = i + tc; c < n; c += 16) A[i * ld + c] = fma(-f, rj[c], A[i * ld + c]);
         }
         __syncthreads();
     }
     if (tid == 0) status[0] = (bad || rmin < cond_tol * rmax) ? 1 : 0;
-    // X = R^-1 (upper triangular), column c by back substitution, one thread per column.  X stays
-    // in LDS: its strict upper part X[i][c] (i < c) goes to the unused strict lower triangle of A
-    // at A[c][i], its diagonal to xd[] (a read-back from global memory per term made this loop 4x
-    // longer than the factorisation).
-    double *xd = sm + n * ld;
-    __syncthreads();
-    for (int c = tid; c < n; c += 256) {
-        xd[c] = 1.0 / A[c * ld + c];
-        for (int i = c - 1; i >= 0; --i) {
-            double acc = A[i * ld + c] * xd[c];                       // k = c
-            for (int k = i + 1; k < c; ++k) acc += A[i * ld + k] * A[c * ld + k];   // X[k][c] at A[c][k]
-            A[c * ld + i] = -acc / A[i * ld + i];
-        }
+    // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
+    for (int e = tid; e < n * n; e += 256) {
+        const int j = e / n, c = e - j * n;
+        if (c == j) xd[j] = 1.0 / sqrt(A[j * ld + j] > 0.0 ? A[j * ld + j] : 1.0);
     }
     __syncthreads();
-    auto X = [&](int i, int c) -> double { return i == c ? xd[c] : (i < c ? A[c * ld + i] : 0.0); };
-    for (int e = tid; e < n * n; e += 256) Rinv[e] = X(e / n, e % n);
+    for (int e = tid; e < n * n; e += 256) {
+        const int j = e / n, c = e - j * n;
+        if (c >= j) A[j * ld + c] *= xd[j];
+    }
+    __syncthreads();
+    // X = R^-1 (upper triangular).  X stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused
+    // strict lower triangle of A at A[c][i], its diagonal to xd[].
+    // Row i of X from the rows below it, all columns c > i at once, one barrier per row:
+    // X[i][c] = -(sum_{i < k <= c} R[i][k] X[k][c]) / R[i][i]; four lanes share a column's sum.  (One thread
+    // per COLUMN doing its whole back substitution was 50 lanes of one wave walking 1200 dependent LDS round
+    // trips: 0.1 ms at n = 50.)
+    const int q4 = tid & 3, col4 = tid >> 2;
+    for (int i = n - 2; i >= 0; --i) {
+        const double *ri = A + i * ld;
+        for (int c0 = i + 1; c0 < n; c0 += 64) {
+            const int c = c0 + col4;
+            double acc = 0.0;
+            if (c < n) {
+                const double *xc = A + c * ld;                          // X[k][c] at A[c][k], k < c
+                for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (c < n && q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
+        }
+        __syncthreads();
+    }
+    // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        if (i < c) A[i * ld + c] = A[c * ld + i];
+        else if (i == c) A[i * ld + i] = xd[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        if (i > c) A[i * ld + c] = 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) Rinv[e] = A[(e / n) * ld + e % n];
     if (Ginv) {
         for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, c = e % n, k0 = i > c ? i : c;
-            double acc = 0.0;
-            for (int k = k0; k < n; ++k) acc += X(i, k) * X(c, k);
-            Ginv[e] = acc;
+            const int i = e / n, c = e - i * n;
+            if (c < i) continue;                                      // symmetric: computed once, written twice
+            const double *xi = A + i * ld, *xc = A + c * ld;
+            double acc0 = 0.0, acc1 = 0.0;
+            int k = c;
+            for (; k + 1 < n; k += 2) {
+                acc0 = fma(xi[k], xc[k], acc0);
+                acc1 = fma(xi[k + 1], xc[k + 1], acc1);
+            }
+            if (k < n) acc0 = fma(xi[k], xc[k], acc0);
+            Ginv[i * n + c] = acc0 + acc1;
+            Ginv[c * n + i] = acc0 + acc1;
         }
     }
 }
