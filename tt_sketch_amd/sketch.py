@@ -65,7 +65,7 @@ def hmt_sketch(tensor: Tensor, rank: TTRank, seed: Optional[int] = None,
     elif tuple(drm.rank[::-1]) != rank:
         raise ValueError(f"Right rank {rank} does not match the rank of the DRM {drm.rank}.")
     sketch = general_sketch(tensor, None, drm, method=SketchMethod.hmt)
-    sketched = TensorTrain(sketch.Psi_cores)
+    sketched = TensorTrain(sketch.device_arrays()[0])     # cores stay in HBM (DevArray; np.asarray(core) copies out)
     return (sketched, drm) if return_drm else sketched
 
 
@@ -94,7 +94,7 @@ def orthogonal_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank,
         raise ValueError(
             f"Right rank {right_rank} does not match the rank of the DRM {right_drm.rank}.")
     sketch = general_sketch(tensor, left_drm, right_drm, method=SketchMethod.orthogonal)
-    sketched = TensorTrain(sketch.Psi_cores)
+    sketched = TensorTrain(sketch.device_arrays()[0])     # cores stay in HBM (DevArray; np.asarray(core) copies out)
     return (sketched, left_drm, right_drm) if return_drm else sketched
 
 
