@@ -28,9 +28,14 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     const int mW = (int)(transposed ? r : l), nW = (int)(transposed ? l : r);
     // lds_mode 1: W lives in LDS, 2: W and V (the global scratch is then unused) -- a rotation is two
     // dependent passes over a column pair, so the latency of where the columns live is the run time
+    // All LDS is dynamic: [sigma^2 (nW doubles) | order (nW ints, padded) | W | V], so that a 100 x 100
+    // factor (2 x 80 KB) still fits next to them in the 160 KB of a CU.
     extern __shared__ double jac_lds[];
-    if (lds_mode >= 1) Wc = jac_lds;
-    if (lds_mode >= 2) V = jac_lds + (size_t)mW * nW;
+    double *s_inv2 = jac_lds;
+    int *s_ord = reinterpret_cast<int *>(jac_lds + nW);
+    double *jac_mat = jac_lds + nW + (nW + 1) / 2;
+    if (lds_mode >= 1) Wc = jac_mat;
+    if (lds_mode >= 2) V = jac_mat + (size_t)mW * nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     __shared__ int s_rot;
     __shared__ double s_smax;
@@ -42,7 +47,9 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     for (int t = tid; t < nW * nW; t += blockDim.x) V[t] = (t / nW == t % nW) ? 1.0 : 0.0;
     __syncthreads();
     const int np = nW + (nW & 1);  // players (one dummy if odd)
-    const double tol = 4.0 * DBL_EPSILON;
+    // LAPACK dgesvj stops at sqrt(m) eps: the computed inner product of two columns of length m carries that
+    // much rounding noise, a tighter bound keeps rotating noise until the sweep limit
+    const double tol = fmax(4.0, sqrt((double)mW)) * DBL_EPSILON;
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) s_rot = 0;
         __syncthreads();
@@ -84,7 +91,6 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
         if (!rot) break;
     }
     // singular values -> reuse the first nW entries of a shared array
-    __shared__ double s_inv2[1024];
     if (tid == 0) s_smax = 0.0;
     __syncthreads();
     for (int j = wave; j < nW; j += nwave) {
@@ -97,7 +103,6 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     __syncthreads();
     if (svd_US) {
         // order the columns by descending singular value (nW <= 1024, one thread)
-        __shared__ int s_ord[1024];
         if (tid == 0) {
             for (int j = 0; j < nW; ++j) s_ord[j] = j;
             for (int a = 1; a < nW; ++a) {
@@ -495,15 +500,16 @@ static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
 {
     static const int off = getenv("TTSK_JACOBI_GLOBAL") ? 1 : 0;
     static int attr_done = 0;
-    const size_t cap = 128 * 1024;                  // + 12.3 KB static in the kernel, 160 KB per CU
+    const size_t cap = 160 * 1024 - 256;            // 160 KB per CU minus the kernel's few static bytes
     const size_t w = (size_t)mW * nW * 8, v = (size_t)nW * nW * 8;
+    const size_t small = ((size_t)nW + (nW + 1) / 2) * 8;          // sigma^2 and the sort order
     int mode = 0;
-    *bytes = 0;
+    *bytes = small;
     if (!off) {
-        if (w + v <= cap) { mode = 2; *bytes = w + v; }
-        else if (w <= cap) { mode = 1; *bytes = w; }
+        if (small + w + v <= cap) { mode = 2; *bytes = small + w + v; }
+        else if (small + w <= cap) { mode = 1; *bytes = small + w; }
     }
-    if (mode && !attr_done) {
+    if (!attr_done) {
         if (hipFuncSetAttribute((const void *)jacobi_pinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)cap) != hipSuccess) {
             set_error("jacobi: cannot raise the dynamic LDS limit");
