@@ -13,6 +13,24 @@
 
 namespace ttsk {
 
+// sum over the 16 lanes of a DPP row, result in every lane: x += ror(x, 8), 4, 2, 1 (v_mov_dpp row_ror)
+template <int CTRL>
+__device__ __forceinline__ double jac_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double x)
+{
+    x += jac_dpp<0x120 + 8>(x);
+    x += jac_dpp<0x120 + 4>(x);
+    x += jac_dpp<0x120 + 2>(x);
+    x += jac_dpp<0x120 + 1>(x);
+    return x;
+}
+
 // ---------------------------------------------------------------- Jacobi SVD pinv
 // W: mW x nW (mW >= nW) column-major in Wc (column j at Wc + j*mW), V: nW x nW column-major.
 // On exit P[i*ldp_i + k*ldp_k] = sum_{j kept} Wc_j[i] * V_j[k] / sigma_j^2.
@@ -39,6 +57,7 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     __shared__ int s_rot;
     __shared__ double s_smax;
+    const int grp = tid >> 4, gl = tid & 15, ngrp = blockDim.x >> 4;
     // load: W = Omega^T (transposed) or Omega
     for (int t = tid; t < mW * nW; t += blockDim.x) {
         int j = t / mW, i = t - j * mW;
@@ -54,7 +73,10 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
         if (tid == 0) s_rot = 0;
         __syncthreads();
         for (int round = 0; round < np - 1; ++round) {
-            for (int pi = wave; pi < np / 2; pi += nwave) {
+            // one column pair per group of 16 lanes (a DPP row): 64 pairs of a round rotate at once and the
+            // three inner products are reduced by four in-register row rotations.  (A whole wave per pair was
+            // four sequential pair steps per round at n = 100, each paying six ds_bpermute stages.)
+            for (int pi = grp; pi < np / 2; pi += ngrp) {
                 int p, q;
                 if (pi == 0) { p = np - 1; q = round; }
                 else { p = (round + pi) % (np - 1); q = (round + np - 1 - pi) % (np - 1); }
@@ -62,24 +84,22 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
                 if (p > q) { int t = p; p = q; q = t; }
                 double *wp = Wc + (size_t)p * mW, *wq = Wc + (size_t)q * mW;
                 double a = 0, b = 0, g = 0;
-                for (int i = lane; i < mW; i += 64) {
+                for (int i = gl; i < mW; i += 16) {
                     double x = wp[i], y = wq[i];
                     a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    a += __shfl_xor(a, o); b += __shfl_xor(b, o); g += __shfl_xor(g, o);
-                }
+                a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
                 if (fabs(g) <= tol * sqrt(a * b) || g == 0.0) continue;
-                if (lane == 0) s_rot = 1;
+                if (gl == 0) s_rot = 1;
                 double zeta = (b - a) / (2.0 * g);
                 double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = lane; i < mW; i += 64) {
+                for (int i = gl; i < mW; i += 16) {
                     double x = wp[i], y = wq[i];
                     wp[i] = c * x - s * y; wq[i] = s * x + c * y;
                 }
                 double *vp = V + (size_t)p * nW, *vq = V + (size_t)q * nW;
-                for (int i = lane; i < nW; i += 64) {
+                for (int i = gl; i < nW; i += 16) {
                     double x = vp[i], y = vq[i];
                     vp[i] = c * x - s * y; vq[i] = s * x + c * y;
                 }

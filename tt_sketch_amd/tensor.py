@@ -479,7 +479,7 @@ class TensorTrain(Tensor):
                 nat.call("ttsk_triu", ctypes.c_void_p(Rc.ptr), r1, r1, 0)
                 A = Rc.T.contiguous()                                # M = Rc^T Qc^T
             if r1 > 1024:
-                return self.round(eps=eps, max_rank=max_rank, orthogonalized=orthogonalized)
+                raise ValueError(f"round_dev: TT rank {r1} > 1024 is beyond the one-workgroup SVD; use round()")
             US, S, Vt = DevArray.empty((r1, r1)), DevArray.empty((r1,)), DevArray.empty((r1, r1))
             nat.call("ttsk_svd_small", ctypes.c_void_p(A.ptr), r1, r1, ctypes.c_void_p(US.ptr),
                      ctypes.c_void_p(S.ptr), ctypes.c_void_p(Vt.ptr), 0)
