@@ -31,29 +31,96 @@ __device__ __forceinline__ double row_sum16(double x)
     return x;
 }
 
+// One Jacobi pair step by a 16-lane group: columns wp, wq (length mW) of W and vp, vq (length nW) of V.
+// IT > 0: mW, nW <= 16 IT -- the columns stay in registers between the inner products and the rotation
+// (one LDS read instead of two) and the loops are straight-line code; IT = 0: any length.
+template <int IT>
+__device__ __forceinline__ void jac_pair(double *wp, double *wq, double *vp, double *vq, const int mW, const int nW,
+                                         const int gl, const double tol2, int *s_rot)
+{
+    constexpr int ITC = IT ? IT : 1;
+    double x[ITC], y[ITC];
+    double a = 0, b = 0, g = 0, a1 = 0, b1 = 0, g1 = 0;
+    if constexpr (IT > 0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = gl + 16 * it;
+            x[it] = i < mW ? wp[i] : 0.0;
+            y[it] = i < mW ? wq[i] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it += 2) {
+            a = fma(x[it], x[it], a); b = fma(y[it], y[it], b); g = fma(x[it], y[it], g);
+            if (it + 1 < IT) {
+                a1 = fma(x[it + 1], x[it + 1], a1); b1 = fma(y[it + 1], y[it + 1], b1); g1 = fma(x[it + 1], y[it + 1], g1);
+            }
+        }
+        a += a1; b += b1; g += g1;
+    } else {
+        for (int i = gl; i < mW; i += 16) {
+            const double xx = wp[i], yy = wq[i];
+            a = fma(xx, xx, a); b = fma(yy, yy, b); g = fma(xx, yy, g);
+        }
+    }
+    a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
+    if (g * g <= tol2 * (a * b) || g == 0.0) return;
+    if (gl == 0) *s_rot = 1;
+    const double zeta = (b - a) / (2.0 * g);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    if constexpr (IT > 0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = gl + 16 * it;
+            if (i < mW) { wp[i] = c * x[it] - s * y[it]; wq[i] = s * x[it] + c * y[it]; }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = gl + 16 * it;
+            x[it] = i < nW ? vp[i] : 0.0;
+            y[it] = i < nW ? vq[i] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = gl + 16 * it;
+            if (i < nW) { vp[i] = c * x[it] - s * y[it]; vq[i] = s * x[it] + c * y[it]; }
+        }
+    } else {
+        for (int i = gl; i < mW; i += 16) {
+            const double xx = wp[i], yy = wq[i];
+            wp[i] = c * xx - s * yy; wq[i] = s * xx + c * yy;
+        }
+        for (int i = gl; i < nW; i += 16) {
+            const double xx = vp[i], yy = vq[i];
+            vp[i] = c * xx - s * yy; vq[i] = s * xx + c * yy;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- Jacobi SVD pinv
 // W: mW x nW (mW >= nW) column-major in Wc (column j at Wc + j*mW), V: nW x nW column-major.
 // On exit P[i*ldp_i + k*ldp_k] = sum_{j kept} Wc_j[i] * V_j[k] / sigma_j^2.
 // With svd_US != nullptr the kernel returns the factors instead of the pseudo-inverse (input taken
 // untransposed, l >= r): US (l x r row-major) = U diag(S), S (r) descending, Vt (r x r row-major).
+template <int LM>
 __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restrict__ omega, int64_t l,
                                                            int64_t r, int transposed, double *Wc,
                                                            double *V, double rcond, double *P,
-                                                           int *rank_out, double *svd_US = nullptr,
-                                                           double *svd_S = nullptr, double *svd_Vt = nullptr,
-                                                           int lds_mode = 0)
+                                                           int *rank_out, double *svd_US,
+                                                           double *svd_S, double *svd_Vt)
 {
     const int mW = (int)(transposed ? r : l), nW = (int)(transposed ? l : r);
-    // lds_mode 1: W lives in LDS, 2: W and V (the global scratch is then unused) -- a rotation is two
-    // dependent passes over a column pair, so the latency of where the columns live is the run time
+    // LM = 1: W lives in LDS, 2: W and V (the global scratch is then unused).  A template parameter, not a
+    // run-time switch: a pointer that may be LDS or global compiles to FLAT loads and stores (67 + 54 of them
+    // in this kernel), several times slower than ds_read / ds_write for data that is in LDS.
     // All LDS is dynamic: [sigma^2 (nW doubles) | order (nW ints, padded) | W | V], so that a 100 x 100
     // factor (2 x 80 KB) still fits next to them in the 160 KB of a CU.
     extern __shared__ double jac_lds[];
     double *s_inv2 = jac_lds;
     int *s_ord = reinterpret_cast<int *>(jac_lds + nW);
     double *jac_mat = jac_lds + nW + (nW + 1) / 2;
-    if (lds_mode >= 1) Wc = jac_mat;
-    if (lds_mode >= 2) V = jac_mat + (size_t)mW * nW;
+    if constexpr (LM >= 1) Wc = jac_mat;
+    if constexpr (LM >= 2) V = jac_mat + (size_t)mW * nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     __shared__ int s_rot;
     __shared__ double s_smax;
@@ -68,7 +135,9 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     const int np = nW + (nW & 1);  // players (one dummy if odd)
     // LAPACK dgesvj stops at sqrt(m) eps: the computed inner product of two columns of length m carries that
     // much rounding noise, a tighter bound keeps rotating noise until the sweep limit
-    const double tol = fmax(4.0, sqrt((double)mW)) * DBL_EPSILON;
+    const double tol = fmax(4.0, sqrt((double)mW)) * DBL_EPSILON, tol2 = tol * tol;
+    const int nm1 = np - 1;
+    const int itc = mW <= 64 ? 4 : (mW <= 128 ? 8 : 0);       // mW >= nW
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) s_rot = 0;
         __syncthreads();
@@ -78,31 +147,18 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
             // four sequential pair steps per round at n = 100, each paying six ds_bpermute stages.)
             for (int pi = grp; pi < np / 2; pi += ngrp) {
                 int p, q;
-                if (pi == 0) { p = np - 1; q = round; }
-                else { p = (round + pi) % (np - 1); q = (round + np - 1 - pi) % (np - 1); }
+                if (pi == 0) { p = nm1; q = round; }
+                else {
+                    p = round + pi; p -= p >= nm1 ? nm1 : 0;
+                    q = round + nm1 - pi; q -= q >= nm1 ? nm1 : 0;
+                }
                 if (p >= nW || q >= nW) continue;
                 if (p > q) { int t = p; p = q; q = t; }
                 double *wp = Wc + (size_t)p * mW, *wq = Wc + (size_t)q * mW;
-                double a = 0, b = 0, g = 0;
-                for (int i = gl; i < mW; i += 16) {
-                    double x = wp[i], y = wq[i];
-                    a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
-                }
-                a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
-                if (fabs(g) <= tol * sqrt(a * b) || g == 0.0) continue;
-                if (gl == 0) s_rot = 1;
-                double zeta = (b - a) / (2.0 * g);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = gl; i < mW; i += 16) {
-                    double x = wp[i], y = wq[i];
-                    wp[i] = c * x - s * y; wq[i] = s * x + c * y;
-                }
                 double *vp = V + (size_t)p * nW, *vq = V + (size_t)q * nW;
-                for (int i = gl; i < nW; i += 16) {
-                    double x = vp[i], y = vq[i];
-                    vp[i] = c * x - s * y; vq[i] = s * x + c * y;
-                }
+                if (itc == 4) jac_pair<4>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
+                else if (itc == 8) jac_pair<8>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
+                else jac_pair<0>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
             }
             __syncthreads();
         }
@@ -530,8 +586,9 @@ static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
         else if (small + w <= cap) { mode = 1; *bytes = small + w; }
     }
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)jacobi_pinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)cap) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)jacobi_pinv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
+            hipFuncSetAttribute((const void *)jacobi_pinv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
+            hipFuncSetAttribute((const void *)jacobi_pinv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) {
             set_error("jacobi: cannot raise the dynamic LDS limit");
             return -1;
         }
@@ -575,9 +632,10 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     size_t jl = 0;
     const int jm = jacobi_lds_mode(mW, nW, &jl);
     if (jm < 0) return TTSK_ERR_HIP;
-    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), jl, st, dev_omega, l, r, transposed, ws,
+    auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_omega, l, r, transposed, ws,
                        ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr, (double *)nullptr,
-                       (double *)nullptr, (double *)nullptr, jm);
+                       (double *)nullptr, (double *)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && host_rank) {
         e = hipMemcpyAsync(host_rank, drank, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -599,8 +657,9 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
     size_t jl = 0;
     const int jm = jacobi_lds_mode(m, n, &jl);
     if (jm < 0) return TTSK_ERR_HIP;
-    hipLaunchKernelGGL(jacobi_pinv_kernel, dim3(1), dim3(1024), jl, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
-                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt, jm);
+    auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
+                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
