@@ -36,7 +36,7 @@ __device__ __forceinline__ double row_sum16(double x)
 // (one LDS read instead of two) and the loops are straight-line code; IT = 0: any length.
 template <int IT>
 __device__ __forceinline__ void jac_pair(double *wp, double *wq, double *vp, double *vq, const int mW, const int nW,
-                                         const int gl, const double tol2, int *s_rot)
+                                         const int gl, const double tol2, const double tiny2, int *s_rot)
 {
     constexpr int ITC = IT ? IT : 1;
     double x[ITC], y[ITC];
@@ -63,7 +63,10 @@ __device__ __forceinline__ void jac_pair(double *wp, double *wq, double *vp, dou
         }
     }
     a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
-    if (g * g <= tol2 * (a * b) || g == 0.0) return;
+    // both columns at rounding-noise level (norm^2 <= tiny2 = (4 m eps)^2 x the largest column norm^2 of this
+    // sweep): directions the rank rule drops anyway; rotating noise against noise never converges in the
+    // relative sense and kept rank-deficient sketches sweeping until the limit.  W = A V holds regardless.
+    if (g * g <= tol2 * (a * b) || g == 0.0 || (a <= tiny2 && b <= tiny2)) return;
     if (gl == 0) *s_rot = 1;
     const double zeta = (b - a) / (2.0 * g);
     const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -139,8 +142,24 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
     const int nm1 = np - 1;
     const int itc = mW <= 64 ? 4 : (mW <= 128 ? 8 : 0);       // mW >= nW
     for (int sweep = 0; sweep < 60; ++sweep) {
-        if (tid == 0) s_rot = 0;
+        if (tid == 0) { s_rot = 0; s_smax = 0.0; }
         __syncthreads();
+        // largest column norm^2 of this sweep (fixed reduction order: per-column sums, then one thread)
+        for (int j = grp; j < nW; j += ngrp) {
+            const double *wj = Wc + (size_t)j * mW;
+            double a = 0;
+            for (int i = gl; i < mW; i += 16) a = fma(wj[i], wj[i], a);
+            a = row_sum16(a);
+            if (gl == 0) s_inv2[j] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double mx = 0;
+            for (int j = 0; j < nW; ++j) mx = fmax(mx, s_inv2[j]);
+            s_smax = mx;
+        }
+        __syncthreads();
+        const double tiny = 4.0 * mW * DBL_EPSILON, tiny2 = tiny * tiny * s_smax;
         for (int round = 0; round < np - 1; ++round) {
             // one column pair per group of 16 lanes (a DPP row): 64 pairs of a round rotate at once and the
             // three inner products are reduced by four in-register row rotations.  (A whole wave per pair was
@@ -156,9 +175,9 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
                 if (p > q) { int t = p; p = q; q = t; }
                 double *wp = Wc + (size_t)p * mW, *wq = Wc + (size_t)q * mW;
                 double *vp = V + (size_t)p * nW, *vq = V + (size_t)q * nW;
-                if (itc == 4) jac_pair<4>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
-                else if (itc == 8) jac_pair<8>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
-                else jac_pair<0>(wp, wq, vp, vq, mW, nW, gl, tol2, &s_rot);
+                if (itc == 4) jac_pair<4>(wp, wq, vp, vq, mW, nW, gl, tol2, tiny2, &s_rot);
+                else if (itc == 8) jac_pair<8>(wp, wq, vp, vq, mW, nW, gl, tol2, tiny2, &s_rot);
+                else jac_pair<0>(wp, wq, vp, vq, mW, nW, gl, tol2, tiny2, &s_rot);
             }
             __syncthreads();
         }
