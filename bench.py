@@ -234,7 +234,7 @@ def main():
         elapsed = float(t[0])
 
     # latency of ONE sketch issued alone (batch 1, nothing else in flight), for reference
-    single_ms, api_ms = None, None
+    single_ms, api_ms, cores_per_s_r53 = None, None, None
     if world == 1:
         one = (ctypes.c_void_p * plan.d)(*[ptrs[i] for i in range(plan.d)])
         for _ in range(3):
@@ -260,6 +260,22 @@ def main():
                 if it >= 2:
                     best = min(best, 1e3 * (time.perf_counter() - t1))
             api_ms[name] = best
+        # the reference's other oversampling choice, right rank = left + 3 ("STTA+3", scripts/plot_timings.py:110-124;
+        # SURVEY 8d asks for it next to r = 2 l): same batch, device-sampled DRM, 20 timed passes
+        r53 = L_RANK + 3
+        right53 = TensorTrainDRM(r53, shape, True, seed=2)
+        plan53 = TTSketchPlan(tt.shape, tt.rank, left, right53)
+        stride53 = plan53.size + (plan53.size & 1)
+        out53 = DevArray.empty((B * stride53,))
+        for _ in range(3):
+            plan53.run_batch(ptrs, B, out53, stride53, stream=0)
+        nat.call("ttsk_sync", -1)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            plan53.run_batch(ptrs, B, out53, stride53, stream=0)
+        nat.call("ttsk_sync", -1)
+        cores_per_s_r53 = D * B * 20 / (time.perf_counter() - t1)
+        del out53, plan53, right53
         run_on(0)                      # restore the batched result checked below
         nat.call("ttsk_sync", -1)
 
@@ -337,7 +353,8 @@ def main():
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
                                   tts_per_step=B, steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
-                                  t_total_ms_incl_drm_sampling=api_ms, sketch_bytes=plan.size * 8),
+                                  t_total_ms_incl_drm_sampling=api_ms, tt_cores_per_s_right_rank_53=cores_per_s_r53,
+                                  sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
         print(json.dumps(result))
     if dist is not None:
