@@ -580,6 +580,10 @@ def test_resident_tt_arithmetic(tsa):
     assert ad.add(bd).rank == a.add(b).rank
     assert abs(ad.dot(bd) - a.dot(b)) < 1e-13 * a.norm() * b.norm()
     assert abs(ad.norm() - a.norm()) < 1e-13 * a.norm()
+    assert abs(ad.gram_norm() - a.norm()) < 1e-13 * a.norm()
+    near = tsa.TensorTrain([c.copy() for c in a.cores])
+    near.cores[-1] = near.cores[-1] * (1 + 1e-11)
+    assert abs(ad.error(near.to_device(), relative=True) - 1e-11) < 1e-13       # no sqrt(eps) floor
     assert rel((ad * -2.5).to_numpy(), -2.5 * a.to_numpy()) < 1e-15
     assert rel((ad - bd * 0.5).to_numpy(), a.to_numpy() - 0.5 * b.to_numpy()) < 1e-14
     assert abs(ad.error(bd) - a.error(b)) < 1e-12 * a.norm()

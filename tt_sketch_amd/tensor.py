@@ -398,11 +398,15 @@ class TensorTrain(Tensor):
 
     def norm(self) -> float:
         if self.resident():
-            # Gram chain <x, x> on the device (2 d small products) instead of the QR sweep of the
-            # reference (tensor.py:442-444): every partial Gram matrix is positive semi-definite, so
-            # the relative error stays at a few ulp of ||x||^2 -- and there is no QR per norm.
-            return float(np.sqrt(max(self.dot(self), 0.0)))
+            return float(np.linalg.norm(self.orthogonalize_dev().cores[-1].get()))
         return float(np.linalg.norm(self.orthogonalize().cores[-1]))
+
+    def gram_norm(self) -> float:
+        """sqrt(<x, x>) by the Gram chain (2 d small device products, no QR sweep).  Accurate to a few ulp
+        for a train that is not itself a difference of nearly equal terms -- a direct sum ``a + (-b)`` with
+        a ~ b cancels inside the chain and is only good to sqrt(eps) ||a||; ``norm`` (QR sweep, reference
+        tensor.py:442-444) has no such limit and is what ``error`` uses."""
+        return float(np.sqrt(max(self.dot(self), 0.0)))
 
     def resident(self) -> bool:
         """True if the cores live in HBM only (as ``to_tt`` / ``round_dev`` / an MPO product leave

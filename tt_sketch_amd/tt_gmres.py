@@ -243,17 +243,21 @@ def tt_sum_gmres(A: TTLinearMapSum, b: TensorTrain, max_rank: TTRank,
             out = TensorSum([precond(t) for t in out.tensors])
         return out
 
+    # norms of explicit (rounded) trains: the Gram chain is exact to rounding there and saves a QR sweep
+    def norm(x: TensorTrain) -> float:
+        return x.gram_norm() if x.resident() else x.norm()
+
     rhs = precond(b) if precond is not None else b
-    b_norm = b.norm()
+    b_norm = norm(b)
     t_start = perf_counter()
     res = round_tt_sum(rhs - operator(x0), max_rank=max_rank, method=rounding_method)
-    res_norm = res.norm()
+    res_norm = norm(res)
     beta = res_norm
     basis: List[TensorTrain] = [res / beta]
     H = np.zeros((maxiter + 1, maxiter))
 
     history: Dict[str, Any] = defaultdict(list)
-    history["w_norm"].append(basis[-1].norm())
+    history["w_norm"].append(norm(basis[-1]))
     history["rank"].append(res.rank)
     history["residual_norm"].append(res_norm / b_norm)
     history["step_time"].append(perf_counter() - t_start)
@@ -273,7 +277,7 @@ def tt_sum_gmres(A: TTLinearMapSum, b: TensorTrain, max_rank: TTRank,
         # Gram-Schmidt against the (recent) basis, rounded again
         w = round_tt_sum(w - TensorSum(basis[lo:j + 1]) * H[lo:j + 1, j], eps=delta,
                          max_rank=max_rank, method=rounding_method)
-        H[j + 1, j] = w.norm()
+        H[j + 1, j] = norm(w)
         basis.append(w / H[j + 1, j])
         history["step_time"].append(perf_counter() - t_step)
 
