@@ -199,6 +199,13 @@ int ttsk_sparse_sort_mode(const int64_t *dev_idx_row, size_t N, int64_t n, int64
  * contiguous; P is (r, l) contiguous.  The products A*P / P*B are ttsk_gemm calls. */
 int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
               int *host_rank /* may be NULL */, int stream);
+/* The same in two phases for callers with several independent pseudo-inverses (assemble_sketched_tt,
+ * sketch.py:400-443: one per mode): `begin` queues the fast path on `stream` and returns at once, `end`
+ * waits for that stream, and runs the Jacobi SVD if the fast path was rejected.  One begin per library
+ * stream may be outstanding; arguments of `end` repeat those of `begin`. */
+int ttsk_pinv_begin(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv, int stream);
+int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
+                  int *host_rank /* may be NULL */, int stream);
 /* thin SVD of a small matrix (TensorTrain.round, tensor.py:446-484, after a QR has reduced the
  * unfolding to its triangular factor): A (m, n) row-major, m >= n, n <= 1024, by one-sided Jacobi in
  * one workgroup.  US (m, n) = U diag(S), S (n) descending, Vt (n, n); A = US Vt. */

@@ -75,6 +75,8 @@ def _bind(lib):
         "ttsk_sparse_psi": [P, P, P, S, P, c_int64, P, c_int64, c_int64, P, I],
         "ttsk_sparse_sort_mode": [P, S, c_int64, P, I],
         "ttsk_pinv": [P, c_int64, c_int64, c_double, P, POINTER(I), I],
+        "ttsk_pinv_begin": [P, c_int64, c_int64, c_double, P, I],
+        "ttsk_pinv_end": [P, c_int64, c_int64, c_double, P, POINTER(I), I],
         "ttsk_triu": [P, c_int64, c_int64, I],
         "ttsk_svd_small": [P, c_int64, c_int64, P, P, P, I],
         "ttsk_qr_thin": [P, c_int64, c_int64, I],

@@ -532,10 +532,27 @@ static bool fast_solves()
 }
 
 // pinv(Omega) through the normal equations; 1 = done, 0 = rejected (caller runs the Jacobi SVD)
-static int pinv_cholesky(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st)
+// Two phases, so that the d - 1 pseudo-inverses of an assembly can be in flight on their own streams
+// before the host looks at the first verdict: `begin` queues Gram matrix, factorisation, the product
+// Omega^T G^-1 (speculatively: it is overwritten if the factorisation is rejected) and the copy of the
+// verdict into a pinned per-stream slot; `verdict` waits for the stream and reads it.
+static int *pinv_host_status()
+{
+    static int *p = [] {
+        int *q = nullptr;
+        if (hipHostMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int), hipHostMallocDefault) != hipSuccess) q = nullptr;
+        return q;
+    }();
+    return p;
+}
+static int g_pinv_began[TTSK_NUM_STREAMS];
+
+// 1 = attempt queued, 0 = not applicable, < 0 = error
+static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st)
 {
     const int n = (int)(l <= r ? l : r);
-    if (n > 128) return 0;
+    int *hs = pinv_host_status();
+    if (n > 128 || !hs) return 0;
     double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(3 * n * n + 16) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *G = ws, *Rinv = ws + n * n, *Ginv = ws + 2 * n * n;
@@ -547,16 +564,21 @@ static int pinv_cholesky(const double *omega, int64_t l, int64_t r, double *pinv
     // normal equations square the condition number: accept kappa(Omega) up to ~300 (error ~1e-11)
     rc = launch_chol(G, n, Rinv, Ginv, status, 1.0 / 300.0, st);
     if (rc) return rc;
-    int host_status = 1;
-    TTSK_HIP(hipMemcpyAsync(&host_status, status, sizeof(int), hipMemcpyDeviceToHost, st));
-    TTSK_HIP(hipStreamSynchronize(st));
-    static int trace = [] { const char *e = getenv("TTSK_GEMM_TRACE"); return e ? atoi(e) : 0; }();
-    if (trace) fprintf(stderr, "ttsk_pinv %lld x %lld: normal equations %s\n", (long long)l, (long long)r,
-                       host_status ? "rejected -> Jacobi SVD" : "accepted");
-    if (host_status) return 0;
+    hs[stream] = 1;
+    TTSK_HIP(hipMemcpyAsync(hs + stream, status, sizeof(int), hipMemcpyDeviceToHost, st));
     if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // Omega^T G^-1
     else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // G^-1 Omega^T
     return rc ? rc : 1;
+}
+// 1 = accepted (pinv is final), 0 = rejected
+static int pinv_cholesky_verdict(int64_t l, int64_t r, int stream, hipStream_t st)
+{
+    TTSK_HIP(hipStreamSynchronize(st));
+    const int host_status = pinv_host_status()[stream];
+    static int trace = [] { const char *e = getenv("TTSK_GEMM_TRACE"); return e ? atoi(e) : 0; }();
+    if (trace) fprintf(stderr, "ttsk_pinv %lld x %lld: normal equations %s\n", (long long)l, (long long)r,
+                       host_status ? "rejected -> Jacobi SVD" : "accepted");
+    return host_status ? 0 : 1;
 }
 
 // thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected
@@ -618,8 +640,34 @@ static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
 
 extern "C" {
 
-int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
-              int *host_rank, int stream)
+static double pinv_rcond(int64_t l, int64_t r, double rcond)
+{
+    if (rcond < 0) rcond = DBL_EPSILON;
+    // Rank-decision floor: one-sided Jacobi returns the rounding noise of a numerically rank
+    // deficient Omega as singular values of size ~eps*||Omega||; gelsd's eps*sigma_max rule then
+    // becomes a coin flip and a kept noise direction is amplified by 1/sigma^2.  Anything within
+    // 16*sqrt(max(l,r)) of that noise level is treated as zero (documented in DESIGN.md).
+    const double floor_ = 16.0 * DBL_EPSILON * sqrt((double)(l > r ? l : r));
+    return rcond < floor_ ? floor_ : rcond;
+}
+
+int ttsk_pinv_begin(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_omega && dev_pinv, "ttsk_pinv: NULL argument");
+    TTSK_ARG(l >= 1 && r >= 1, "ttsk_pinv: bad shape (%lld, %lld)", (long long)l, (long long)r);
+    TTSK_ARG((r >= l ? l : r) <= 1024, "ttsk_pinv: min(l, r) = %lld > 1024 unsupported", (long long)(r >= l ? l : r));
+    g_pinv_began[stream] = 0;
+    if (fast_solves() && pinv_rcond(l, r, rcond) <= 1e-4) {
+        const int fr = pinv_cholesky_begin(dev_omega, l, r, dev_pinv, stream, st);
+        if (fr < 0) return fr;
+        g_pinv_began[stream] = fr;
+    }
+    return TTSK_OK;
+}
+
+int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
+                  int *host_rank, int stream)
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(dev_omega && dev_pinv, "ttsk_pinv: NULL argument");
@@ -627,17 +675,10 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     const int transposed = r >= l;
     const int64_t mW = transposed ? r : l, nW = transposed ? l : r;
     TTSK_ARG(nW <= 1024, "ttsk_pinv: min(l, r) = %lld > 1024 unsupported", (long long)nW);
-    if (rcond < 0) rcond = DBL_EPSILON;
-    // Rank-decision floor: one-sided Jacobi returns the rounding noise of a numerically rank
-    // deficient Omega as singular values of size ~eps*||Omega||; gelsd's eps*sigma_max rule then
-    // becomes a coin flip and a kept noise direction is amplified by 1/sigma^2.  Anything within
-    // 16*sqrt(max(l,r)) of that noise level is treated as zero (documented in DESIGN.md).
-    {
-        double floor_ = 16.0 * DBL_EPSILON * sqrt((double)(l > r ? l : r));
-        if (rcond < floor_) rcond = floor_;
-    }
-    if (fast_solves() && rcond <= 1e-4) {
-        const int fr = pinv_cholesky(dev_omega, l, r, dev_pinv, stream, st);
+    rcond = pinv_rcond(l, r, rcond);
+    if (g_pinv_began[stream]) {
+        g_pinv_began[stream] = 0;
+        const int fr = pinv_cholesky_verdict(l, r, stream, st);
         if (fr < 0) return fr;
         if (fr == 1) {
             if (host_rank) *host_rank = (int)(l < r ? l : r);
@@ -662,6 +703,14 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     }
     TTSK_HIP(e);
     return TTSK_OK;
+}
+
+int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
+              int *host_rank, int stream)
+{
+    const int rc = ttsk_pinv_begin(dev_omega, l, r, rcond, dev_pinv, stream);
+    if (rc != TTSK_OK) return rc;
+    return ttsk_pinv_end(dev_omega, l, r, rcond, dev_pinv, host_rank, stream);
 }
 
 int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,

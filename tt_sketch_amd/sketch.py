@@ -21,7 +21,7 @@ from .sketch_dispatch import SketchMethod, general_sketch
 from .sketching_methods.abstract_methods import (CansketchCP, CansketchDense, CansketchSparse,
                                                  CansketchTT)
 from .tensor import Tensor, TensorTrain
-from .utils import ArrayList, TTRank, pinv_dev, process_tt_rank
+from .utils import ArrayList, TTRank, pinv_dev_many, process_tt_rank
 
 DEFAULT_DRM = {
     CansketchDense: DenseGaussianDRM,
@@ -231,11 +231,12 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool
     nstreams = max(1, min(len(Om), nat_streams()))
     sync()
     pending, keep = [], []          # `keep`: operands stay allocated until the streams have drained
+    pinvs = pinv_dev_many(Om, streams=range(nstreams))      # pinv k on stream k % nstreams, verdicts read afterwards
     if direction == "right":
         for k, (P, O) in enumerate(zip(Psi[:-1], Om)):
             r1, n, r2 = P.shape
             st = k % nstreams
-            Pc, Oi = P.contiguous(st), pinv_dev(O, stream=st)
+            Pc, Oi = P.contiguous(st), pinvs[k]
             keep += [Pc, Oi]
             pending.append(contract("ij,jk->ik", Pc.reshape(r1 * n, r2), Oi, stream=st).reshape(r1, n, O.shape[0]))
         pending.append(Psi[-1])
@@ -244,7 +245,7 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool
         for k, (P, O) in enumerate(zip(Psi[1:], Om)):
             r1, n, r2 = P.shape
             st = k % nstreams
-            Pc, Oi = P.contiguous(st), pinv_dev(O, stream=st)
+            Pc, Oi = P.contiguous(st), pinvs[k]
             keep += [Pc, Oi]
             pending.append(contract("ij,jk->ik", Oi, Pc.reshape(r1, n * r2), stream=st).reshape(O.shape[1], n, r2))
     else:

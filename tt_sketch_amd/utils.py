@@ -88,6 +88,25 @@ def pinv_dev(Omega, rcond=None, stream=0) -> DevArray:
     return P
 
 
+def pinv_dev_many(Omegas, rcond=None, streams=None):
+    """pinv of several independent matrices, one library stream each: all fast-path attempts are queued
+    before the host waits for the first verdict (``ttsk_pinv_begin`` / ``ttsk_pinv_end``)."""
+    streams = list(streams) if streams is not None else list(range(min(len(Omegas), nat.NUM_STREAMS)))
+    rc = -1.0 if rcond is None else float(rcond)
+    out = [None] * len(Omegas)
+    for lo in range(0, len(Omegas), len(streams)):           # one outstanding begin per stream
+        group = []
+        for k, st in zip(range(lo, min(lo + len(streams), len(Omegas))), streams):
+            Om = as_dev(Omegas[k], st).contiguous(st)
+            P = DevArray.empty((Om.shape[1], Om.shape[0]))
+            nat.call("ttsk_pinv_begin", ctypes.c_void_p(Om.ptr), Om.shape[0], Om.shape[1], rc, ctypes.c_void_p(P.ptr), st)
+            group.append((k, st, Om, P))
+        for k, st, Om, P in group:
+            nat.call("ttsk_pinv_end", ctypes.c_void_p(Om.ptr), Om.shape[0], Om.shape[1], rc, ctypes.c_void_p(P.ptr), None, st)
+            out[k] = P
+    return out
+
+
 def _like_input(result: DevArray, *inputs):
     return result if any(isinstance(x, DevArray) for x in inputs) else result.get()
 
