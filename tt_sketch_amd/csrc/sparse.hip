@@ -144,6 +144,143 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
     }
 }
 
+
+// MFMA form of the same sum for mode-sorted input (or a single slice): one slice of Psi is the long-K
+// product (val o L_slice)^T R_slice over the nonzeros of the slice, so a wave walks its stretch of the
+// sorted nonzero list four at a time -- lane (x = l & 15, q = l >> 4) holds val[e_q] L[e_q][x] and
+// R[e_q][x], the operand layout of v_mfma_f64_16x16x4 -- and accumulates TL x TR tiles.  The rows are
+// gathered through the mode permutation: perm is read 2 D k-blocks ahead, the rows it names D k-blocks
+// ahead (two rings, so neither level of the dependent gather stalls the wave).  A k-block that contains a
+// slice boundary (rare: slices are long when this kernel is chosen) is replayed one nonzero at a time.
+// Slices that straddle two waves meet in Psi through fp64 atomics, as in the scatter kernel; with ONE
+// slice (Omega, first / last mode) every wave would hit the same l x r addresses, so there the partial
+// sums go to `part` (one l x r block per wave) and sparse_part_reduce_kernel adds them.
+template <int TL, int TR, bool PERM>
+__global__ __launch_bounds__(256) void sparse_psi_mfma_kernel(const double *__restrict__ val, const int64_t *__restrict__ idx,
+                                                              const int64_t *__restrict__ perm, size_t N,
+                                                              const double *__restrict__ Lv, int l,
+                                                              const double *__restrict__ Rv, int r, int64_t n,
+                                                              double *__restrict__ psi, size_t chunk,
+                                                              double *__restrict__ part)
+{
+    constexpr int D = 6;
+    const int lane = threadIdx.x & 63, x16 = lane & 15, kq = lane >> 4;
+    const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t beg = wv * chunk;
+    if (beg >= N) return;
+    const size_t end = beg + chunk < N ? beg + chunk : N;
+    const int nblk = (int)((end - beg + 3) >> 2);
+    v4d acc[TL][TR];
+#pragma unroll
+    for (int i = 0; i < TL; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][j][t] = 0.0;
+    long long cur = idx ? -1 : 0;
+
+    auto flush = [&](long long k) {
+#pragma unroll
+        for (int i = 0; i < TL; ++i)
+#pragma unroll
+            for (int j = 0; j < TR; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int a = 16 * i + 4 * t + (lane >> 4), c = 16 * j + (lane & 15);
+                    if (a < l && c < r) {
+                        if (part) part[wv * (size_t)(l * r) + (size_t)a * r + c] = acc[i][j][t];
+                        else if (acc[i][j][t] != 0.0) unsafeAtomicAdd(&psi[((size_t)a * n + k) * r + c], acc[i][j][t]);
+                    }
+                    acc[i][j][t] = 0.0;
+                }
+    };
+
+    long long pe[D];                       // nonzero number of this lane's position, k-blocks b + D .. b + 2 D - 1
+    double ra[D][TL], rb[D][TR], rv[D];    // rows of L and R, entries, of k-blocks b .. b + D - 1
+    long long rk[D];
+    bool rok[D];
+    auto load_perm = [&](int b, int d) {
+        const size_t pos = beg + 4 * (size_t)b + kq;
+        pe[d] = pos < end ? (PERM ? perm[pos] : (long long)pos) : -1;
+    };
+    auto load_rows = [&](int d) {
+        const long long e = pe[d];
+        const bool ok = e >= 0;
+        const size_t ee = ok ? (size_t)e : 0;
+        rok[d] = ok;
+        rv[d] = ok ? val[ee] : 0.0;
+        rk[d] = (ok && idx) ? idx[ee] : 0;
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const int a = 16 * i + x16;
+            ra[d][i] = (ok && a < l) ? (Lv ? Lv[ee * l + a] : 1.0) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            const int c = 16 * j + x16;
+            rb[d][j] = (ok && c < r) ? (Rv ? Rv[ee * r + c] : 1.0) : 0.0;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_perm(d, d);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { load_rows(d); load_perm(D + d, d); }
+
+    const int rounds = (nblk + D - 1) / D;
+    for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double a[TL], b[TR];
+#pragma unroll
+            for (int i = 0; i < TL; ++i) a[i] = ra[d][i] * rv[d];
+#pragma unroll
+            for (int j = 0; j < TR; ++j) b[j] = rb[d][j];
+            const long long kk = rk[d];
+            const bool ok = rok[d];
+            // refill: rows of k-block (it + 1) D + d through the perm entry fetched a round ago, then its successor
+            load_rows(d);
+            load_perm((it + 2) * D + d, d);
+            if (__ballot(ok && kk != cur) == 0ull) {
+#pragma unroll
+                for (int i = 0; i < TL; ++i)
+#pragma unroll
+                    for (int j = 0; j < TR; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            } else {
+                for (int q = 0; q < 4; ++q) {
+                    const int okq = __shfl((int)ok, 16 * q);
+                    const long long kq_slice = __shfl(kk, 16 * q);
+                    if (!okq) continue;
+                    if (kq_slice != cur) {
+                        if (cur >= 0) flush(cur);
+                        cur = kq_slice;
+                    }
+#pragma unroll
+                    for (int i = 0; i < TL; ++i) {
+                        const double am = kq == q ? a[i] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < TR; ++j) acc[i][j] = mfma16(am, b[j], acc[i][j]);
+                    }
+                }
+            }
+        }
+    }
+    if (cur >= 0) flush(cur);
+}
+
+// out[t] += sum_w part[w][t]: one workgroup per output element, fixed summation order
+__global__ __launch_bounds__(256) void sparse_part_reduce_kernel(const double *__restrict__ part, size_t nparts, int lr,
+                                                                 double *__restrict__ out)
+{
+    const int t = blockIdx.x;
+    double acc = 0.0;
+    for (size_t w = threadIdx.x; w < nparts; w += 256) acc += part[w * (size_t)lr + t];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[t] += (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 __global__ void iota_kernel(int64_t *p, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -234,6 +371,42 @@ int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int
     TTSK_ARG(l >= 1 && r >= 1 && n >= 1, "ttsk_sparse_psi: bad shape");
     TTSK_ARG(dev_idx_row || n == 1, "ttsk_sparse_psi: a NULL index row means a single slice (n = 1)");
     if (N == 0) return TTSK_OK;
+    // MFMA kernel: small ranks, and either one slice or mode-sorted input with long slices
+    static int mfma_on = [] { const char *e = getenv("TTSK_SPARSE_MFMA"); return e ? atoi(e) : 1; }();
+    const bool single = dev_idx_row == nullptr || n == 1;
+    if (mfma_on && l <= 32 && r <= 32 && N < (1ull << 40) && (single || (dev_perm && N / (size_t)n >= 32))) {
+        const int tl = l <= 16 ? 1 : 2, tr = r <= 16 ? 1 : 2;
+        // waves: ~8 per SIMD for the scatter case, one per SIMD slot pair when every wave leaves a partial block
+        const size_t want = single ? 2048 : 16384;
+        size_t chunk = ((N + want - 1) / want + 3) & ~(size_t)3;
+        if (chunk < 256) chunk = 256;
+        const size_t waves = (N + chunk - 1) / chunk, blocks = (waves + 3) / 4;
+        double *part = nullptr;
+        if (single) {
+            part = (double *)scratch(stream, SCRATCH_MISC, waves * (size_t)(l * r) * 8);
+            if (!part) return TTSK_ERR_HIP;
+        }
+        const int64_t *idxp = single ? nullptr : dev_idx_row;
+#define TTSK_PSI_GO(TL, TR)                                                                                              \
+        do {                                                                                                           \
+            if (dev_perm) hipLaunchKernelGGL((sparse_psi_mfma_kernel<TL, TR, true>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                                             dev_val, idxp, dev_perm, N, dev_Lv, (int)l, dev_Rv, (int)r, n, dev_psi, chunk, part); \
+            else hipLaunchKernelGGL((sparse_psi_mfma_kernel<TL, TR, false>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+                                    dev_val, idxp, dev_perm, N, dev_Lv, (int)l, dev_Rv, (int)r, n, dev_psi, chunk, part); \
+        } while (0)
+        if (tl == 1 && tr == 1) TTSK_PSI_GO(1, 1);
+        else if (tl == 1) TTSK_PSI_GO(1, 2);
+        else if (tr == 1) TTSK_PSI_GO(2, 1);
+        else TTSK_PSI_GO(2, 2);
+#undef TTSK_PSI_GO
+        TTSK_LAUNCH_CHECK();
+        if (single) {
+            const int lr = (int)(l * r);
+            hipLaunchKernelGGL(sparse_part_reduce_kernel, dim3((unsigned)lr), dim3(256), 0, st, part, waves, lr, dev_psi);
+            TTSK_LAUNCH_CHECK();
+        }
+        return TTSK_OK;
+    }
     const size_t lds = (size_t)64 * (l + r + 1) * 8;
     TTSK_ARG(lds <= 64 * 1024, "ttsk_sparse_psi: l + r = %lld too large for the staging buffer",
              (long long)(l + r));
