@@ -634,3 +634,32 @@ def test_gmres_sketched_rounding(tsa, method):
         tt_sum_gmres(A, tsa.TensorTrain.random((6, 5, 4, 4), 2, seed=0), max_rank=4)
     with pytest.raises(ValueError):
         tt_sum_gmres(A, b, max_rank=4, rounding_method="nope", maxiter=1)
+
+
+@pytest.mark.parametrize("N,n,l,r", [(1000, 7, 10, 15), (5000, 3, 20, 30), (777, 1, 16, 16), (4096, 11, 1, 9),
+                                     (300, 2, 33, 5), (64, 40, 4, 4)])
+def test_sparse_psi_kernels_against_numpy(tsa, N, n, l, r):
+    """ttsk_sparse_psi (sparse_sketch.py:8-36): the MFMA form (sorted, long slices, ranks <= 32), its
+    single-slice form with per-wave partial blocks, and the scatter kernel (short slices / larger rank)
+    against a NumPy scatter-add; including a missing left factor (first mode)."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(N + n)
+    idx = rng.integers(0, n, N).astype(np.int64)
+    val = rng.standard_normal(N)
+    Lv, Rv = rng.standard_normal((N, l)), rng.standard_normal((N, r))
+    perm = np.argsort(idx, kind="stable").astype(np.int64)
+    d_idx, d_val, d_perm = DevArray.from_host(idx), DevArray.from_host(val), DevArray.from_host(perm)
+    d_L, d_R = DevArray.from_host(Lv), DevArray.from_host(Rv)
+    for use_L in (True, False):
+        ll = l if use_L else 1
+        want = np.zeros((ll, n, r))
+        np.add.at(want, (slice(None), idx, slice(None)),
+                  (val[:, None, None] * (Lv[:, :, None] if use_L else 1.0) * Rv[:, None, :]).transpose(1, 0, 2))
+        out = DevArray.zeros((ll, n, r))
+        nat.call("ttsk_sparse_psi", ctypes.c_void_p(d_val.ptr), ctypes.c_void_p(d_idx.ptr) if n > 1 else None,
+                 ctypes.c_void_p(d_perm.ptr) if n > 1 else None, ctypes.c_size_t(N),
+                 ctypes.c_void_p(d_L.ptr) if use_L else None, ll, ctypes.c_void_p(d_R.ptr), r, n,
+                 ctypes.c_void_p(out.ptr), 0)
+        assert rel(out.get(), want) < 1e-13
