@@ -448,9 +448,17 @@ __device__ __forceinline__ void st16(double *p, double x, double y)
 // PA / PB paired 32-blocks and an optional single 16-block per side.
 // NSUB > 1: the wave works on the sub-th of NSUB equal pieces of the workgroup's chunk (small
 // outputs: every wave owns the whole tile set and its own stretch of kappa, one slab per wave).
-template <int PA, int SA, int PB, int SB, int D, bool GEN, int NSUB>
+// GEN = 2: generic tiles whose kappa is contiguous on BOTH sides (the first-mode unfolding of a dense
+// tensor against a k-contiguous sketching matrix): one 16-byte load per tile and lane brings kappa =
+// 8 i + 2 kq and 8 i + 2 kq + 1, i.e. the fragments of two k-blocks -- the x halves are one k-block
+// (kappa 0, 2, 4, 6 of the eight), the y halves the other; any split of the sum is fine as long as both
+// operands use the same one.  Half the vector-memory instructions and 64 instead of 32 contiguous bytes
+// per row and instruction.
+template <int PA, int SA, int PB, int SB, int D, int GEN, int NSUB>
 __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int row0, const int col0, const int sub)
 {
+    constexpr bool GK = GEN == 2;
+    static_assert(!GK || TTSK_R_M16, "16-byte generic tiles use the 16x16x4 form");
     constexpr int TM = 2 * PA + SA, TN = 2 * PB + SB;
     const int lane = threadIdx.x & 63;
     const int x16 = lane & 15, kq = lane >> 4;
@@ -461,8 +469,9 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
     const int64_t k0 = (int64_t)ci * a.chunk + (NSUB > 1 ? sub * piece : 0);
     const int64_t kend = ((int64_t)ci + 1) * a.chunk < a.K ? ((int64_t)ci + 1) * a.chunk : a.K;
     const int64_t len = kend - k0 < 0 ? 0 : (kend - k0 < piece ? kend - k0 : piece);
-    const int nkb_lane = (int)(len > kq ? (len - kq + 3) >> 2 : 0);
-    const int KB = (int)((len + 3) >> 2);
+    // GK: a "k-block" below is eight kappa (two MFMA k-blocks), this lane's are 8 i + 2 kq (+ 1); len is even
+    const int nkb_lane = GK ? (int)(len > 2 * kq ? (len - 2 * kq + 7) >> 3 : 0) : (int)(len > kq ? (len - kq + 3) >> 2 : 0);
+    const int KB = GK ? (int)((len + 7) >> 3) : (int)((len + 3) >> 2);
     const int64_t tile_row0 = (int64_t)mtile * a.M;                 // first row of this tile in A
     const int rows_here = (int)(a.Mtot - tile_row0 < a.M ? a.Mtot - tile_row0 : a.M);
     // operand origins of this workgroup (rebase: + the chunk's kappa offset; every out-of-range lane is
@@ -472,12 +481,12 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(uniform_ptr(a.B[prob]) + b_org, a.rebase ? (int64_t)OOB_OFF : a.b_extent * 8);
 
     // per-lane walk over kappa = k0 + kq + 4 i: byte offsets of A's and B's kappa part
-    const int64_t kap = (a.rebase ? 0 : k0) + kq;
+    const int64_t kap = (a.rebase ? 0 : k0) + (GK ? 2 * kq : kq);
     const int64_t ko0 = (a.rebase || a.Ki == a.K) ? 0 : kap / a.Ki;
     int ki = (int)(kap - ko0 * a.Ki);
     uint32_t offA = (uint32_t)((ko0 * a.a_ko + (int64_t)ki * a.a_ki) * 8);
     uint32_t offB = (uint32_t)((ko0 * a.b_ko + (int64_t)ki * a.b_ki) * 8);
-    const uint32_t stepA = (uint32_t)(4 * a.a_ki * 8), stepB = (uint32_t)(4 * a.b_ki * 8);
+    const uint32_t stepA = (uint32_t)((GK ? 8 : 4) * a.a_ki * 8), stepB = (uint32_t)((GK ? 8 : 4) * a.b_ki * 8);
     const uint32_t wrapA = (uint32_t)((a.a_ko - a.Ki * a.a_ki) * 8), wrapB = (uint32_t)((a.b_ko - a.Ki * a.b_ki) * 8);
     const int Ki = (int)a.Ki;
     // column (element) offsets inside a kappa row; elements past M / N are masked per lane
@@ -509,10 +518,18 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
     }
 
     double ringA[D][TM], ringB[D][TN];
+    double ringA2[GK ? D : 1][TM], ringB2[GK ? D : 1][TN];      // GK: the odd kappa of each 16-byte load
     int kb_load = 0;
     auto issue = [&](int d) {
         const bool ok = kb_load < nkb_lane;
-        if constexpr (GEN) {
+        if constexpr (GK) {
+#pragma unroll
+            for (int p = 0; p < TM; ++p) {
+                const double2 v = ld16(raT[p], (ok && okA[p]) ? xA + offA : OOB_OFF, 0);
+                ringA[d][p] = v.x;
+                ringA2[d][p] = v.y;
+            }
+        } else if constexpr (GEN) {
 #pragma unroll
             for (int p = 0; p < TM; ++p) ringA[d][p] = ld8(raT[p], (ok && okA[p]) ? xA + offA : OOB_OFF, 0);
         } else {
@@ -524,7 +541,14 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
             }
             if (SA) ringA[d][2 * PA] = ld8(ra, (ok && rowA[PA] != OOB_OFF) ? rowA[PA] + offA : OOB_OFF, 0);
         }
-        if constexpr (GEN) {
+        if constexpr (GK) {
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                const double2 v = ld16(rbT[q], (ok && okB[q]) ? xB + offB : OOB_OFF, 0);
+                ringB[d][q] = v.x;
+                ringB2[d][q] = v.y;
+            }
+        } else if constexpr (GEN) {
 #pragma unroll
             for (int q = 0; q < TN; ++q) ringB[d][q] = ld8(rbT[q], (ok && okB[q]) ? xB + offB : OOB_OFF, 0);
         } else {
@@ -537,7 +561,7 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
             if (SB) ringB[d][2 * PB] = ld8(rb, (ok && colB[PB] != OOB_OFF) ? colB[PB] + offB : OOB_OFF, 0);
         }
         ++kb_load;
-        ki += 4;
+        ki += GK ? 8 : 4;
         offA += stepA;
         offB += stepB;
         const bool wrap = ki >= Ki;
@@ -558,12 +582,16 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
 
     SK_STAMP(1);
     auto kblock = [&](int d, bool more) {
-        double af[TM], bf[TN], rB[TN][4];
+        double af[TM], bf[TN], rB[TN][4], af2[TM], bf2[TN];
 #pragma unroll
-        for (int p = 0; p < TM; ++p) af[p] = ringA[d][p];
+        for (int p = 0; p < TM; ++p) {
+            af[p] = ringA[d][p];
+            if (GK) af2[p] = ringA2[d][p];
+        }
 #pragma unroll
         for (int q = 0; q < TN; ++q) {
             bf[q] = ringB[d][q];
+            if (GK) bf2[q] = ringB2[d][q];
             if (!TTSK_R_M16) rot4(ringB[d][q], rB[q]);
         }
         if (more) issue(d);
@@ -573,6 +601,7 @@ __device__ __forceinline__ void skinny_r_wave_impl(const SkinnyR &a, const int r
             for (int q = 0; q < TN; ++q) {
                 if (TTSK_R_M16) {
                     acc[p][q] = mfma16(af[p], bf[q], acc[p][q]);
+                    if (GK) acc[p][q] = mfma16(af2[p], bf2[q], acc[p][q]);
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[p][q][t] = mfma4(af[p], rB[q][t], acc[p][q][t]);
@@ -633,8 +662,9 @@ template <int PA, int SA, int PB, int SB, int D, int NSUB = 1>
 __device__ __forceinline__ void skinny_r_wave(const SkinnyR &a, const int row0, const int col0, const int sub = 0)
 {
     // two straight-line variants (a branch inside the k-block loop would break its software pipeline)
-    if (a.a_gen) skinny_r_wave_impl<PA, SA, PB, SB, D, true, NSUB>(a, row0, col0, sub);
-    else skinny_r_wave_impl<PA, SA, PB, SB, D, false, NSUB>(a, row0, col0, sub);
+    if (a.a_gen == 2) skinny_r_wave_impl<PA, SA, PB, SB, D, 2, NSUB>(a, row0, col0, sub);
+    else if (a.a_gen) skinny_r_wave_impl<PA, SA, PB, SB, D, 1, NSUB>(a, row0, col0, sub);
+    else skinny_r_wave_impl<PA, SA, PB, SB, D, 0, NSUB>(a, row0, col0, sub);
 }
 
 // outputs of at most SKR_KSPLIT_TILES tiles: kappa split over the 8 waves instead of the tiles

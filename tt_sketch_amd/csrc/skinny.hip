@@ -144,6 +144,12 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
         r.b_ko = d.a_ko; r.b_ki = d.a_ki; small_ = d.M; r.b_n = d.a_m; r.b_gen = !a_pair;
     }
     if (r.a_gen || r.b_gen) r.a_gen = r.b_gen = 1;     // one generic variant: both sides through plain tiles
+    // ... or its 16-byte form when kappa is contiguous on both sides (single-level kappa, even strides / K,
+    // 16-byte aligned bases)
+    static int gk_on = [] { const char *e = getenv("TTSK_R_GK"); return e ? atoi(e) : 1; }();
+    bool gk = gk_on && r.a_gen && d.Ko == 1 && r.a_ki == 1 && r.b_ki == 1 && !(K & 1) && !(r.a_m & 1) && !(r.b_n & 1);
+    for (int b = 0; b < nb && gk; ++b)
+        if (((uintptr_t)A[b] | (uintptr_t)B[b]) & 15) gk = false;
     // a lane's row offset inside a tile (15 rows) has to fit 32 bits next to the kappa walk
     if (15 * r.a_m * 8 >= (1ll << 31) || 15 * r.b_n * 8 >= (1ll << 31)) return 0;
     r.Mtot = big;
@@ -160,12 +166,13 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
     r.K = K;
     if (d.Ko > 1 && r.a_ko == d.Ki * r.a_ki && r.b_ko == d.Ki * r.b_ki) r.Ki = K;   // uniform walk
     r.rebase = r.Ki == K ? 1 : 0;
+    if (gk && r.rebase) r.a_gen = r.b_gen = 2;
     { const char *e = getenv("TTSK_SK_STAMPS"); r.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     r.a_extent = (big - 1) * r.a_m + (d.Ko - 1) * r.a_ko + (d.Ki - 1) * r.a_ki + 1;
     r.b_extent = (r.N - 1) * r.b_n + (d.Ko - 1) * r.b_ko + (d.Ki - 1) * r.b_ki + 1;
     const int cus = num_cu() / nb > 0 ? num_cu() / nb : 1;
     const int64_t want_chunks = cus / r.m_tiles > 0 ? cus / r.m_tiles : 1;
-    r.chunk = cdiv(cdiv(K, want_chunks), 4) * 4;
+    r.chunk = cdiv(cdiv(K, want_chunks), 8) * 8;
     if (r.chunk < 64) r.chunk = 64;
     if (r.rebase) {
         // per-workgroup origins: 32-bit offsets only have to span one chunk and one row tile; shorter
@@ -175,7 +182,7 @@ static int try_r(const ttsk_gemm_desc &d, int nb, const double *const *A, const 
             const int64_t sb = ((r.b_gen ? 16 * r.b_n : 144) + (chunk + 64) * r.b_ki) * 8;
             return sa > sb ? sa : sb;
         };
-        while (span(r.chunk) >= (1ll << 32) - 64 && r.chunk > 64) r.chunk = cdiv(r.chunk / 2, 4) * 4;
+        while (span(r.chunk) >= (1ll << 32) - 64 && r.chunk > 64) r.chunk = cdiv(r.chunk / 2, 8) * 8;
         if (span(r.chunk) >= (1ll << 32) - 64) return 0;
     }
     const int chunks = (int)cdiv(K, r.chunk);
