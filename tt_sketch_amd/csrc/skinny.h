@@ -255,10 +255,11 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
                 const double *wk = wl_lane + kb * 4 * LDW;
                 double af[NTC], as = 0.0, sf[STR ? STR : 1];
                 constexpr int NFULL = STR ? NT - 1 : NT;
+                constexpr int LASTT = NT > 0 ? NT - 1 : 0;       // the partial tile (strips)
 #pragma unroll
                 for (int p = 0; p < NFULL; ++p) af[p] = wk[16 * p];
 #pragma unroll
-                for (int q = 0; q < STR; ++q) sf[q] = wk[16 * (NT - 1) + 4 * q - soff4];
+                for (int q = 0; q < STR; ++q) sf[q] = wk[16 * LASTT + 4 * q - soff4];
                 if (SH) as = wk[soffS];
                 double rA[4], rB[4];
                 const double sA = NT ? ringA[d] : 0.0, sB = SH ? ringB[d] : 0.0;
@@ -274,7 +275,7 @@ __device__ __forceinline__ void skinny_s_wave_impl(const SkinnyS &a, const doubl
 #pragma unroll
                     for (int p = 0; p < NFULL; ++p) accA[p] = mfma16(af[p], sA, accA[p]);
 #pragma unroll
-                    for (int q = 0; q < STR; ++q) accA[NT - 1][q] = mfma4(sf[q], sA, accA[NT - 1][q]);
+                    for (int q = 0; q < STR; ++q) accA[LASTT][q] = mfma4(sf[q], sA, accA[LASTT][q]);
                     if (SH) accB = mfma16(as, sB, accB);
                 } else {
 #pragma unroll
