@@ -169,6 +169,31 @@ __device__ __forceinline__ void ndtri_block(bool live, double u, size_t g, doubl
     __syncthreads();
 }
 
+// The same split for a whole LDS tile of samples: the producer loop stores scale * ndtri(u) for central
+// samples and parks the tail samples' u in their slot, queueing the slot number; after ONE barrier the
+// queue is drained by all threads, full waves of tail code.  (ndtri_block above pays three barriers per
+// 256 samples, i.e. per column of a row tile.)
+__device__ __forceinline__ void tile_sample(double u, int slot, double scale, double *tile, unsigned short *q, int *qn)
+{
+    const double expm2 = 0.13533528323661269189;
+    if (u > expm2 && u <= 1.0 - expm2) {
+        tile[slot] = scale * ndtri_dev(u);
+    } else {
+        tile[slot] = u;
+        q[atomicAdd(qn, 1)] = (unsigned short)slot;
+    }
+}
+__device__ __forceinline__ void tile_drain(double scale, double *tile, const unsigned short *q, const int *qn)
+{
+    __syncthreads();
+    const int n = *qn;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int slot = q[i];
+        tile[slot] = scale * ndtri_dev(tile[slot]);
+    }
+    __syncthreads();
+}
+
 __global__ void hash_kernel(uint64_t *v, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -210,8 +235,10 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const int64_t *__restr
                                                           int rank_min, int rank, uint64_t seed,
                                                           double *__restrict__ out)
 {
-    extern __shared__ double tile[];                         // [256][rank] + rank salts
+    extern __shared__ double tile[];                         // [256][rank] + rank salts + tail queue
     uint64_t *salt = (uint64_t *)(tile + 256 * rank);
+    unsigned short *tq = (unsigned short *)(salt + rank);    // [256 * rank] slots of tail samples
+    __shared__ int tq_n;
     const int tid = threadIdx.x;
     if (tid < rank) salt[tid] = mix64((uint64_t)(rank_min + tid)) + seed;
     __syncthreads();
@@ -219,13 +246,16 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const int64_t *__restr
         const size_t e = e0 + tid;
         const bool live = e < N;
         const uint64_t flat = live ? flat_index(idx, im, e) : 0;
+        if (tid == 0) tq_n = 0;
+        __syncthreads();
         for (int j = 0; j < rank; ++j) {
             const uint64_t h = mix64(flat + salt[j]);
             const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
             if (MODE == 0) tile[tid * rank + j] = __longlong_as_double(bits);
-            else ndtri_block(live, live ? mant_unit(bits) : 0.5, (size_t)(tid * rank + j), 1.0, tile);
+            else if (live) tile_sample(mant_unit(bits), tid * rank + j, 1.0, tile, tq, &tq_n);
         }
-        __syncthreads();
+        if (MODE == 0) __syncthreads();
+        else tile_drain(1.0, tile, tq, &tq_n);
         const size_t cnt = (N - e0 < 256 ? N - e0 : 256) * (size_t)rank;
         for (size_t t = tid; t < cnt; t += 256) out[e0 * rank + t] = tile[t];
         __syncthreads();
@@ -260,16 +290,35 @@ __global__ void sign_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t
     for (int j = 0; j < w; ++j) out[e * (size_t)w + j] = (OUT)ws[(size_t)(rank_min + j) * N + e];
 }
 
-__global__ void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
+__global__ __launch_bounds__(256) void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
-        const size_t i = i0 + threadIdx.x;
-        uint64_t h = mix64((uint64_t)i + key);
-        h = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
-        double u = mant_unit(h);
-        if (u == 0.0) u = 0x1p-53;
-        ndtri_block(i < n, u, i, scale, out);
+    constexpr int PER = 8;                                   // samples per thread and tile
+    __shared__ double tile[256 * PER];
+    __shared__ unsigned short tq[256 * PER];
+    __shared__ int tq_n;
+    const size_t stride = (size_t)gridDim.x * 256 * PER;
+    for (size_t i0 = (size_t)blockIdx.x * 256 * PER; i0 < n; i0 += stride) {
+        if (threadIdx.x == 0) tq_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int slot = threadIdx.x + 256 * k;
+            const size_t i = i0 + slot;
+            if (i < n) {
+                uint64_t h = mix64((uint64_t)i + key);
+                h = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
+                double u = mant_unit(h);
+                if (u == 0.0) u = 0x1p-53;
+                tile_sample(u, slot, scale, tile, tq, &tq_n);
+            }
+        }
+        tile_drain(scale, tile, tq, &tq_n);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const size_t i = i0 + threadIdx.x + 256 * k;
+            if (i < n) out[i] = tile[threadIdx.x + 256 * k];
+        }
+        __syncthreads();
     }
 }
 
@@ -285,9 +334,14 @@ static void launch_sample(const int64_t *idx, const IndexMap &im, size_t N, int 
                           double *out, hipStream_t st)
 {
     if (w <= 32) {
+        static bool attr_done = false;       // 256 x w tile + salts + tail queue: up to 82 KB at w = 32
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)sample_rows_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_done = true;
+        }
         size_t blocks = (N + 255) / 256;
         if (blocks > (1u << 16)) blocks = 1u << 16;
-        hipLaunchKernelGGL((sample_rows_kernel<MODE>), dim3((unsigned)blocks), dim3(256), (size_t)(256 * w + w) * 8, st,
+        hipLaunchKernelGGL((sample_rows_kernel<MODE>), dim3((unsigned)blocks), dim3(256), (size_t)(256 * w + w) * 8 + (size_t)256 * w * 2, st,
                            idx, im, N, rank_min, w, seed, out);
     } else {
         hipLaunchKernelGGL((sample_kernel<MODE>), dim3(grid_for(N * (size_t)w, 256, 1u << 20)), dim3(256), 0, st, idx,
@@ -426,7 +480,7 @@ int ttsk_fill_normal(double *dev_out, size_t n, uint64_t seed, double scale, int
     TTSK_STREAM(st, stream);
     if (n == 0) return TTSK_OK;
     uint64_t key = mix64(seed ^ 0x9E3779B97F4A7C15ULL);
-    hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for(n, 256, 1u << 16)), dim3(256), 0, st, dev_out, n,
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for(n, 2048, 1u << 16)), dim3(256), 0, st, dev_out, n,
                        key, scale);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
