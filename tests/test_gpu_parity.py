@@ -165,6 +165,14 @@ def test_sampler_properties(tsa):
     srt = np.sort(b.ravel())
     from scipy.special import ndtr
     assert np.max(np.abs(ndtr(srt) - (np.arange(srt.size) + 0.5) / srt.size)) < 0.01
+    # every width of the row-tile kernel (incl. 26..32: tile + tail queue beyond 64 KB of LDS) and the wide
+    # kernel (> 32) against the oracle: <= 4 ulp, ragged last tile
+    sub = idx[:, :1003]
+    for w in (1, 7, 25, 26, 32, 33, 40):
+        got = flg.inds_to_normal(sub, shape, 3, 3 + w, 99)
+        want = orc.inds_to_normal(sub, shape, 3, 3 + w, 99)
+        assert got.shape == want.shape == (1003, w)
+        assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)) < 4 * 2.3e-16 * 4
     s = flg.inds_to_sparse_sign(idx, shape, 12, 0, 12, 3, 7)
     assert set(np.unique(s)) <= {-1, 0, 1} and np.all(np.sum(s != 0, axis=1) == 3)
     assert np.array_equal(s, orc.inds_to_sparse_sign(idx, shape, 12, 0, 12, 3, 7))
