@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 D, N_MODE, S_IN, L_RANK, R_RANK = 6, 200, 100, 50, 100
+HBM_TBS = 8.0            # TB/s, MI355X_MICROARCH.md (achievable stream rates measured here: 4.6-5.4)
 PEAK_F64_MFMA_TF = 78.6   # AMD MI355X data sheet (fp64 matrix); not listed in MI355X_MICROARCH.md
 
 
@@ -310,6 +311,23 @@ def main():
                                       share_ms=ms.value / reps)
         os.environ.pop("TTSK_SINGLE_STREAM", None)
         nat.call("ttsk_prof_enable", 0)
+        # both roofs per class: algorithmic bytes of one launch (operands read once, result written once, the
+        # shared DRM core once per launch) against HBM_TBS, flops against the matrix peak; the lower roof binds
+        s_, l_, r_, n_ = S_IN, L_RANK, R_RANK, N_MODE
+        mb = {labels[0]: B * (s_ * n_ * s_ + r_ * n_ * s_) + s_ * r_ * B,
+              labels[1]: B * (r_ * n_ * s_ + s_ * r_) + r_ * n_ * r_,
+              labels[2]: B * (s_ * n_ * s_ + l_ * n_ * s_) + s_ * l_ * B,
+              labels[3]: B * (l_ * n_ * s_ + s_ * l_) + l_ * n_ * l_,
+              labels[4]: B * (l_ * n_ * s_ + l_ * n_ * r_ + s_ * r_)}
+        for label, doubles in mb.items():
+            if label in classes:
+                c = classes[label]
+                c["algorithmic_mb_per_launch"] = doubles * 8e-6
+                c["algorithmic_tb_per_s"] = doubles * 8 / (c["avg_us"] * 1e-6) * 1e-12
+                hbm_roof_tf = c["gflop_per_launch"] * 1e9 / (doubles * 8) * HBM_TBS      # TF/s if bytes moved at HBM_TBS
+                c["roof_tflops"] = min(PEAK_F64_MFMA_TF, hbm_roof_tf)
+                c["bound"] = "hbm" if hbm_roof_tf < PEAK_F64_MFMA_TF else "mfma"
+                c["frac_of_roof"] = c["tflops"] / c["roof_tflops"]
         dom = max(classes, key=lambda k: classes[k]["share_ms"])
         probe = ctypes.c_double()
         nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
