@@ -112,6 +112,8 @@ def cpu_baseline(shape, cores, lcores, rcores, budget_s=12.0):
 
 
 def main():
+    # dmabuf IPC is the only mode the host driver supports (RCCL between processes); must precede HIP start-up
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
