@@ -137,7 +137,7 @@ def main():
     from tt_sketch_amd import _native as nat
     from tt_sketch_amd import TensorTrain, TensorTrainDRM
     from tt_sketch_amd.tt_fused import TTSketchPlan
-    nat.call("ttsk_init", local_rank)
+    nat.call("ttsk_init", int(os.environ.get("TTSK_BENCH_DEVICE", local_rank)))   # override: rehearsals on a one-GPU box
 
     dist = None
     if world > 1:
