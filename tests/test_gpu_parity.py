@@ -671,3 +671,34 @@ def test_sparse_psi_kernels_against_numpy(tsa, N, n, l, r):
                  ctypes.c_void_p(d_L.ptr) if use_L else None, ll, ctypes.c_void_p(d_R.ptr), r, n,
                  ctypes.c_void_p(out.ptr), 0)
         assert rel(out.get(), want) < 1e-13
+
+
+def test_c_abi_argument_errors(tsa):
+    """Error convention of the boundary: bad arguments come back as TTSK_ERR_ARG ->
+    ValueError with a message, never as a fault; the library stays usable afterwards."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    A = DevArray.from_host(np.eye(4))
+    out = DevArray.empty((4, 4))
+    S = DevArray.empty((4,))
+    P = ctypes.c_void_p
+    with pytest.raises(ValueError):          # m < n
+        nat.call("ttsk_svd_small", P(A.ptr), 2, 4, P(out.ptr), P(S.ptr), P(out.ptr), 0)
+    with pytest.raises(ValueError):          # NULL output
+        nat.call("ttsk_svd_small", P(A.ptr), 4, 4, None, P(S.ptr), P(out.ptr), 0)
+    with pytest.raises(ValueError):          # bad shape
+        nat.call("ttsk_pinv_begin", P(A.ptr), 0, 4, -1.0, P(out.ptr), 0)
+    with pytest.raises(ValueError):          # NULL input
+        nat.call("ttsk_pinv", None, 4, 4, -1.0, P(out.ptr), None, 0)
+    with pytest.raises(ValueError):          # thin QR needs m >= n
+        nat.call("ttsk_qr_thin", P(A.ptr), 2, 4, 0)
+    with pytest.raises(ValueError):
+        nat.call("ttsk_triu", None, 4, 4, 0)
+    with pytest.raises(ValueError):          # l + r beyond the staging buffer of the scatter kernel / NULL values
+        nat.call("ttsk_sparse_psi", None, None, None, ctypes.c_size_t(4), None, 1, None, 1, 1, P(out.ptr), 0)
+    with pytest.raises((ValueError, RuntimeError)):   # stream index out of range
+        nat.call("ttsk_triu", P(A.ptr), 4, 4, 999)
+    # still alive
+    nat.call("ttsk_pinv", P(A.ptr), 4, 4, -1.0, P(out.ptr), None, 0)
+    assert rel(out.get(), np.eye(4)) < 1e-14
