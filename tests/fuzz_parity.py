@@ -40,6 +40,20 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
         data = ("cp", [rng.standard_normal((n, R)) for n in shape])
     ld = orc.random_tt_drm(shape, lr, False, rng)
     rd = orc.random_tt_drm(shape, rr, True, rng)
+    tol = 1e-11
+    if kind == "sparse" and rng.random() < 0.6:      # hash DRMs (Gaussian or sign), with rank slices
+        d_ = len(shape)
+        lo_l = tuple(int(x) for x in rng.integers(0, 3, d_ - 1))
+        lo_r = tuple(int(x) for x in rng.integers(0, 3, d_ - 1))
+        hi_l = tuple(a + b for a, b in zip(lo_l, lr))
+        hi_r = tuple(a + b for a, b in zip(lo_r, rr))
+        if rng.random() < 0.5:
+            ld = orc.HashGaussDrm(int(rng.integers(0, 2**31)), shape, False, lo_l, hi_l)
+            rd = orc.HashGaussDrm(int(rng.integers(0, 2**31)), shape, True, lo_r, hi_r)
+            tol = 1e-10                              # device ndtri within a few ulp of the oracle's
+        else:
+            ld = orc.HashSignDrm(int(rng.integers(0, 2**31)), shape, False, hi_l, lo_l, hi_l)
+            rd = orc.HashSignDrm(int(rng.integers(0, 2**31)), shape, True, hi_r, lo_r, hi_r)
     try:
         T = make_tensor(*data)
         L, Rm = make_drm(ld), make_drm(rd)
@@ -51,7 +65,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
             if fused is not None:
                 errs += [rel(a.get(), c) for a, c in zip(fused[0] + fused[1], oP + oO)]
         n_cases += 1
-        if max(errs) > 1e-11:
+        if max(errs) > tol:
             bad += 1
             print("MISMATCH", kind, shape, s, lr, rr, max(errs), flush=True)
     except Exception as e:
