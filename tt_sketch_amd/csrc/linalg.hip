@@ -481,21 +481,18 @@ __global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__rest
     double *B = sm, *S = sm + n * ld;
     for (int e = tid; e < n * n; e += 256) B[(e / n) * ld + e % n] = Qtop[e];
     __syncthreads();
+    // only the signs are needed: every thread derives the modified pivot itself and the trailing update
+    // uses the unscaled column, so a step is one barrier (it was three plus a one-thread stretch)
+    const int ti = tid >> 4, tc = tid & 15;
     for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            double sgn = B[j * ld + j] >= 0.0 ? -1.0 : 1.0;
-            if (square && j == n - 1) sgn = -sgn;
-            S[j] = sgn;
-            B[j * ld + j] -= sgn;
-        }
-        __syncthreads();
-        const double pinv = 1.0 / B[j * ld + j];
-        for (int i = j + 1 + tid; i < n; i += 256) B[i * ld + j] *= pinv;
-        __syncthreads();
-        const int w = n - j - 1;
-        for (int e = tid; e < w * w; e += 256) {
-            const int i = j + 1 + e / w, c = j + 1 + e % w;
-            B[i * ld + c] -= B[i * ld + j] * B[j * ld + c];
+        double sgn = B[j * ld + j] >= 0.0 ? -1.0 : 1.0;
+        if (square && j == n - 1) sgn = -sgn;
+        if (tid == 0) S[j] = sgn;
+        const double pinv = 1.0 / (B[j * ld + j] - sgn);
+        const double *bj = B + j * ld;
+        for (int i = j + 1 + ti; i < n; i += 16) {
+            const double f = B[i * ld + j] * pinv;
+            for (int c = j + 1 + tc; c < n; c += 16) B[i * ld + c] = fma(-f, bj[c], B[i * ld + c]);
         }
         __syncthreads();
     }
