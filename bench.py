@@ -140,6 +140,11 @@ def main():
     nat.call("ttsk_init", int(os.environ.get("TTSK_BENCH_DEVICE", local_rank)))   # override: rehearsals on a one-GPU box
 
     dist = None
+    comm_on = world > 1 or bool(os.environ.get("TTSK_BENCH_FORCE_COMM"))   # rehearsal: the collective path with one rank
+    if world == 1 and comm_on:
+        uid = (ctypes.c_char * 128)()
+        nat.call("ttsk_comm_unique_id", uid)
+        nat.call("ttsk_comm_init", uid, 0, 1)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -167,7 +172,7 @@ def main():
     stride = plan.size + (plan.size & 1)            # even spacing keeps every sketch 16-byte aligned
     outs = [DevArray.empty((B * stride,)) for _ in range(inflight)]
     out = outs[0]
-    sums = [DevArray.empty((plan.size,)) for _ in range(inflight)] if world > 1 else None
+    sums = [DevArray.empty((plan.size,)) for _ in range(inflight)] if comm_on else None
     keep, flat = [], []
     for t in tts:
         p1, k1 = plan.core_pointers(t)
@@ -183,9 +188,13 @@ def main():
         slot = counter[0] % inflight
         counter[0] += 1
         run_on(slot)
-        if world > 1:
+        if comm_on:
             # the B partial sketches of this rank are summed locally, then ONE all-reduce of one sketch
-            # (32 MB) per step makes every rank hold the sketch of the world * B term sum
+            # (32 MB) per step makes every rank hold the sketch of the world * B term sum.  All collectives go
+            # to one dedicated stream in step order (no two in flight on different streams of one communicator);
+            # the all-reduce of step s overlaps the products of step s + 1 on the other stream pair.
+            cs = nat.NUM_STREAMS - 1
+            nat.call("ttsk_stream_wait", 2 * slot, cs)       # sums[slot] is free again once its last all-reduce is done
             if plan.size % 2 == 0:
                 nat.call("ttsk_sum_slices", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr), B,
                          ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 0, 2 * slot)
@@ -193,12 +202,13 @@ def main():
                 for b in range(B):
                     nat.call("ttsk_axpby", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr + 8 * b * stride),
                              1.0, 1.0 if b else 0.0, ctypes.c_size_t(plan.size), 2 * slot)
-            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(sums[slot].ptr), ctypes.c_size_t(plan.size), 2 * slot)
+            nat.call("ttsk_stream_wait", cs, 2 * slot)
+            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
 
     for _ in range(inflight):
         step_eager()
     nat.call("ttsk_sync", -1)
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and not comm_on
     graphs = []
     if use_graph:
         # one captured graph per in-flight slot: both chains' fork / join over the slot's stream pair
@@ -379,7 +389,9 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
+    if comm_on:
         nat.call("ttsk_comm_destroy")
+    if dist is not None:
         dist.destroy_process_group()
     return result
 

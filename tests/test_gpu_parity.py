@@ -702,3 +702,20 @@ def test_c_abi_argument_errors(tsa):
     # still alive
     nat.call("ttsk_pinv", P(A.ptr), 4, 4, -1.0, P(out.ptr), None, 0)
     assert rel(out.get(), np.eye(4)) < 1e-14
+
+
+def test_bench_collective_path_with_one_rank():
+    """bench.py's multi-GPU step (local sum of the rank's sketches, all-reduce on the dedicated stream, stream
+    waits around the reused buffers) rehearsed with a communicator of one rank; child process, time limit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TTSK_BENCH_FORCE_COMM="1")
+    try:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu", "--steps", "6", "--warmup", "2",
+                              "--batch", "4"], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL communicator set-up did not finish in time on this box")
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tts_per_step"] == 4
