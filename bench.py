@@ -191,19 +191,21 @@ def main():
         if comm_on:
             # the B partial sketches of this rank are summed locally, then ONE all-reduce of one sketch
             # (32 MB) per step makes every rank hold the sketch of the world * B term sum.  All collectives go
-            # to one dedicated stream in step order (no two in flight on different streams of one communicator);
-            # the all-reduce of step s overlaps the products of step s + 1 on the other stream pair.
+            # together with the local sum to one dedicated stream in step order (no two collectives in flight on
+            # different streams of one communicator); both overlap the products of step s + 1 on the other stream pair.
             cs = nat.NUM_STREAMS - 1
-            nat.call("ttsk_stream_wait", 2 * slot, cs)       # sums[slot] is free again once its last all-reduce is done
+            nat.call("ttsk_stream_wait", cs, 2 * slot)       # the step's products are queued on stream 2 slot
             if plan.size % 2 == 0:
                 nat.call("ttsk_sum_slices", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr), B,
-                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 0, 2 * slot)
+                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 0, cs)
             else:
                 for b in range(B):
                     nat.call("ttsk_axpby", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr + 8 * b * stride),
-                             1.0, 1.0 if b else 0.0, ctypes.c_size_t(plan.size), 2 * slot)
-            nat.call("ttsk_stream_wait", cs, 2 * slot)
+                             1.0, 1.0 if b else 0.0, ctypes.c_size_t(plan.size), cs)
             nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
+            # this slot's streams may touch outs[slot] / sums[slot] again only after its own sum + all-reduce; the
+            # wait is queued now, so it names exactly this all-reduce and not the next step's
+            nat.call("ttsk_stream_wait", 2 * slot, cs)
 
     for _ in range(inflight):
         step_eager()
