@@ -226,6 +226,12 @@ int ttsk_comm_unique_id(void *host_id128);                 /* rank 0: 128-byte i
 int ttsk_comm_init(const void *host_id128, int rank, int nranks);
 int ttsk_comm_allreduce_sum(double *dev_buf, size_t n, int stream);
 int ttsk_comm_reduce_sum(double *dev_buf, size_t n, int root, int stream);
+/* every rank's n doubles in rank order into dev_recv (n * nranks doubles): placement of the blocks of a
+ * rank-sharded sketch (blocked_stream_sketch, sketch.py:364-397,446-473 -- disjoint blocks, no sum) */
+int ttsk_comm_allgather(const double *dev_send, double *dev_recv, size_t n, int stream);
+int ttsk_comm_allreduce_max(double *dev_buf, size_t n, int stream);   /* elementwise max, in place */
+/* A failed ttsk_comm_init leaves no communicator behind (the call can be repeated, and the process
+ * exits cleanly); destroy is a no-op without one. */
 int ttsk_comm_destroy(void);
 
 #ifdef __cplusplus

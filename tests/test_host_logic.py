@@ -137,3 +137,82 @@ def test_tt_svd_host():
     assert low.rank == (2, 2, 2)
     best1 = np.linalg.svd(Y.reshape(5, -1), compute_uv=False)
     assert np.linalg.norm(low.to_numpy() - Y) >= np.sqrt(np.sum(best1[2:] ** 2)) - 1e-12
+
+
+def test_pool_reuse_is_stream_ordered():
+    """device.py hands a released buffer out again only to the same stream, or after every stream that
+    may still be touching it has been drained (cross-stream reuse)."""
+    from tt_sketch_amd import device
+    saved = (set(nat._dirty), list(nat._stream_gen))
+    try:
+        nat._dirty.clear()
+        nat._mark("ttsk_axpby", (None, None, 1.0, 1.0, 0, 0))        # work on stream 0 only
+        tag0 = nat.dirty_snapshot()
+        assert set(tag0) == {0}
+        assert device._reusable(tag0, 0) and not device._reusable(tag0, 3)
+        nat._mark("ttsk_gemm", (None, None, None, None, None, 3))    # a multi-stream region opens
+        nat._mark("ttsk_tt_sketch", (None,) * 14 + (4,))             # forks a helper on stream 5
+        tag = nat.dirty_snapshot()
+        assert set(tag) == {0, 3, 4, 5}
+        assert not any(device._reusable(tag, s) for s in range(nat.NUM_STREAMS))
+        nat._stream_gen[3] += 1                                      # as ttsk_sync(3) does
+        nat._dirty.discard(3)
+        assert not device._reusable(tag, 0)
+        for s in range(nat.NUM_STREAMS):                             # as ttsk_sync(-1) does
+            nat._stream_gen[s] += 1
+        nat._dirty.clear()
+        assert all(device._reusable(tag, s) for s in range(nat.NUM_STREAMS))
+        assert device._size_class(100) == 256 and device._size_class(9 << 20) == 10 << 20
+    finally:
+        nat._dirty.clear()
+        nat._dirty.update(saved[0])
+        nat._stream_gen[:] = saved[1]
+
+
+def _rdv_worker(rank, world, directory, out):
+    from tt_sketch_amd.rendezvous import FileRendezvous
+    r = FileRendezvous(rank, world, directory=directory, timeout=30)
+    got = r.broadcast(b"\x01" * 128 if rank == 0 else None)
+    parts = r.allgather(bytes([rank]) * 3)
+    r.barrier()
+    r.close()
+    out.put((rank, got == b"\x01" * 128, parts == [bytes([k]) * 3 for k in range(world)]))
+
+
+def test_file_rendezvous_carries_the_id_between_processes(tmp_path):
+    """The torch-free exchange of the 128-byte RCCL id (bench.py, RcclComm.from_env)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdv_worker, args=(r, 3, str(tmp_path / "rdv"), q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True), (2, True, True)]
+
+
+def test_failed_comm_init_leaves_the_process_exit_clean():
+    """ttsk_comm_init with a bad rank / without a device returns an error code, leaves no
+    communicator behind (destroy is a no-op, init can be called again) and the interpreter exits 0
+    (round 1: the only N = 2 run died in `double free or corruption` after a failed init)."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from tt_sketch_amd import _native as nat
+lib = nat.lib()
+uid = (ctypes.c_char * 128)()
+rcs = [lib.ttsk_comm_init(uid, 5, 2), lib.ttsk_comm_init(uid, -1, 2), lib.ttsk_comm_init(None, 0, 1)]
+assert all(rc != 0 for rc in rcs), rcs
+assert lib.ttsk_comm_destroy() == 0
+assert lib.ttsk_comm_allreduce_sum(None, 4, 0) != 0          # no communicator: an error, not a crash
+assert lib.ttsk_comm_init(uid, 7, 3) != 0 and lib.ttsk_comm_destroy() == 0
+print("clean")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    assert "clean" in out.stdout

@@ -82,6 +82,7 @@ def _bind(lib):
         "ttsk_qr_thin": [P, c_int64, c_int64, I],
         "ttsk_comm_unique_id": [P], "ttsk_comm_init": [P, I, I],
         "ttsk_comm_allreduce_sum": [P, S, I], "ttsk_comm_reduce_sum": [P, S, I, I],
+        "ttsk_comm_allgather": [P, P, S, I], "ttsk_comm_allreduce_max": [P, S, I],
         "ttsk_comm_destroy": [],
     }
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
@@ -123,16 +124,61 @@ def check(rc):
 
 
 _sync_epoch = 0
+# Which library streams have had work queued since they were last drained, and how often each has
+# been drained: device.py tags a released buffer with this so that it is handed out again only to a
+# user on the same stream, or after the streams that may still be touching it have been synchronised.
+_stream_gen = [0] * NUM_STREAMS
+_dirty = set()
+# entry points whose LAST argument is the library stream their work is queued on
+_STREAM_LAST = frozenset((
+    "ttsk_memset", "ttsk_d2d", "ttsk_gemm", "ttsk_copy_strided", "ttsk_axpby", "ttsk_sum_slices",
+    "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
+    "ttsk_fill_normal", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
+    "ttsk_sparse_sort_mode", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
+    "ttsk_qr_thin", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
+_BLOCKING = frozenset(("ttsk_h2d", "ttsk_d2h"))          # return only after their stream has drained
+_TWO_STREAMS = frozenset(("ttsk_tt_sketch", "ttsk_tt_sketch_batch"))   # fork a helper on stream + 1, joined back
 
 
 def sync_epoch() -> int:
-    """Number of device-wide synchronisations so far (device.py recycles a large buffer only after
-    one has happened since its release)."""
+    """Number of device-wide synchronisations so far."""
     return _sync_epoch
+
+
+def dirty_snapshot() -> dict:
+    """{stream: drain generation} of every stream with work queued since its last drain."""
+    return {s: _stream_gen[s] for s in _dirty}
+
+
+def drained_since(stream: int, gen: int) -> bool:
+    return _stream_gen[stream] > gen
+
+
+def _mark(name, args):
+    if name in _STREAM_LAST:
+        s = int(args[-1])
+        if 0 <= s < NUM_STREAMS:
+            _dirty.add(s)
+            if name in _TWO_STREAMS:
+                _dirty.add((s + 1) % NUM_STREAMS)
 
 
 def call(name, *args):
     global _sync_epoch
+    _mark(name, args)                      # before the call: a failing call may have queued part of its work
     check(getattr(lib(), name)(*args))
-    if name == "ttsk_sync" and args and int(args[0]) < 0:
-        _sync_epoch += 1
+    if name == "ttsk_sync" and args:
+        s = int(args[0])
+        if s < 0:
+            _sync_epoch += 1
+            for i in range(NUM_STREAMS):
+                _stream_gen[i] += 1
+            _dirty.clear()
+        elif s < NUM_STREAMS:
+            _stream_gen[s] += 1
+            _dirty.discard(s)
+    elif name in _BLOCKING:
+        s = int(args[-1])
+        if 0 <= s < NUM_STREAMS:
+            _stream_gen[s] += 1
+            _dirty.discard(s)

@@ -40,7 +40,18 @@ int ttsk_comm_init(const void *host_id128, int rank, int nranks)
     TTSK_ARG(g_comm == nullptr, "ttsk_comm_init: communicator already exists");
     ncclUniqueId id;
     memcpy(&id, host_id128, 128);
-    TTSK_NCCL(ncclCommInitRank(&g_comm, nranks, id, rank));
+    // The handle goes to the global only once the communicator is complete: a failed init must leave
+    // the library exactly as it was (no half-built handle for ttsk_comm_destroy or a later call to
+    // find).  RCCL 2.27 frees its own state and nulls the handle when ncclCommInitRank fails; a
+    // non-null handle next to an error would be a communicator it still owns, and is aborted here.
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&c, nranks, id, rank);
+    if (r != ncclSuccess) {
+        if (c) (void)ncclCommAbort(c);
+        ttsk::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, ncclGetErrorString(r));
+        return TTSK_ERR_COMM;
+    }
+    g_comm = c;
     g_nranks = nranks;
     return TTSK_OK;
 }
@@ -64,12 +75,36 @@ int ttsk_comm_reduce_sum(double *dev_buf, size_t n, int root, int stream)
     return TTSK_OK;
 }
 
+/* Every rank's n doubles, in rank order, into recv (n * nranks doubles): the placement step of a
+ * rank-sharded sketch (blocked_stream_sketch, sketch.py:364-397,446-473: DRM rank slices give
+ * disjoint blocks of Psi / Omega, assembled by placement -- no sum). */
+int ttsk_comm_allgather(const double *dev_send, double *dev_recv, size_t n, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(g_comm, "ttsk_comm_allgather: communicator not initialised");
+    TTSK_ARG(dev_send && dev_recv, "ttsk_comm_allgather: NULL buffer");
+    if (n == 0) return TTSK_OK;
+    TTSK_NCCL(ncclAllGather(dev_send, dev_recv, n, ncclDouble, g_comm, st));
+    return TTSK_OK;
+}
+
+/* max over ranks of every element, in place (the bench's max-over-ranks clock) */
+int ttsk_comm_allreduce_max(double *dev_buf, size_t n, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(g_comm, "ttsk_comm_allreduce_max: communicator not initialised");
+    if (n == 0) return TTSK_OK;
+    TTSK_NCCL(ncclAllReduce(dev_buf, dev_buf, n, ncclDouble, ncclMax, g_comm, st));
+    return TTSK_OK;
+}
+
 int ttsk_comm_destroy(void)
 {
     if (g_comm) {
-        ncclCommDestroy(g_comm);
-        g_comm = nullptr;
+        ncclComm_t c = g_comm;
+        g_comm = nullptr;          // cleared first: a failing destroy must not leave a dangling handle
         g_nranks = 0;
+        TTSK_NCCL(ncclCommDestroy(c));
     }
     return TTSK_OK;
 }

@@ -23,80 +23,78 @@ from . import _native as nat
 _F64 = np.dtype(np.float64)
 
 
-# Large allocations are recycled: hipMalloc / hipFree of GB-sized buffers cost 10-100 ms each (the
-# dense-tensor path allocates several per sketch and was swinging between 80 and 500 ms per call).
-# hipFree waits for the device; a recycled buffer gets the same guarantee by being handed out again
-# only after a device-wide ttsk_sync has happened since its release (nat.sync_epoch()).
-_POOL_MIN = 8 << 20          # bytes; below: the small-buffer pool further down
-_POOL_CAP = 48 << 30         # bytes kept at most
-_pool: "dict[int, list]" = {}   # rounded size -> [(release_epoch, ptr), ...]
-_pool_bytes = 0
+# Device buffers are recycled instead of hipFree'd: hipMalloc / hipFree of GB-sized buffers cost
+# 10-100 ms each (the dense-tensor path allocates several per sketch and was swinging between 80 and
+# 500 ms per call), and every hipFree is a device-wide wait (28 of the 35 ms of an orthogonal_sketch
+# at the north-star shape went there, 60 small temporaries).
+#
+# Reuse is stream-ordered.  A released buffer is tagged with the library streams that had work in
+# flight at that moment (``nat.dirty_snapshot()``: a superset of the streams that can still be reading
+# or writing it).  It is handed out again only when every one of those streams has been drained since,
+# or is the stream the new owner says it will use first (``DevArray.empty(..., stream=)``, default 0):
+# work queued later on the same stream is ordered behind the old owner's.  So the single-stream paths
+# recycle at once, and whatever is released inside a multi-stream region (assemble_sketched_tt,
+# pinv_dev_many, contract(..., stream=k) temporaries) waits for that region's closing sync().
+_POOL_MIN = 8 << 20          # bytes; from here on sizes are rounded to 2 MB instead of powers of two
+_POOL_CAP = 48 << 30         # bytes kept at most (large classes)
+_SMALL_CAP = 2 << 30         # bytes kept at most (small classes)
+_SCAN = 16                   # entries of a size class examined per request
+_pool: "dict[int, list]" = {}   # size class -> [(tag, ptr), ...], most recently released last
+_pool_bytes = {True: 0, False: 0}     # large / small
 
 
-def _pool_round(nbytes: int) -> int:
-    return (int(nbytes) + (2 << 20) - 1) & ~((2 << 20) - 1)
-
-
-def _pool_take(size: int):
-    global _pool_bytes
-    lst = _pool.get(size)
-    if lst:
-        epoch = nat.sync_epoch()
-        for i, (rel, ptr) in enumerate(lst):
-            if rel < epoch:
-                del lst[i]
-                _pool_bytes -= size
-                return ptr
-    return None
-
-
-def _pool_give(size: int, ptr: int) -> None:
-    global _pool_bytes
-    _pool.setdefault(size, []).append((nat.sync_epoch(), ptr))
-    _pool_bytes += size
-    while _pool_bytes > _POOL_CAP:          # drop the largest class first
-        big = max((k for k, v in _pool.items() if v), default=None)
-        if big is None:
-            break
-        _, old = _pool[big].pop(0)
-        _pool_bytes -= big
-        nat.lib().ttsk_free(ctypes.c_void_p(old))
-
-
-# Small buffers (the temporaries of the Python-level paths: 60 per orthogonal_sketch) are recycled
-# at once, by power-of-two size class: every hipFree is a device-wide wait (28 of the 35 ms of an
-# orthogonal_sketch at the north-star shape went there).  Immediate reuse is safe for stream-ordered
-# use, which is how DevArrays are used: the library's Python layer works on stream 0 (the one-call TT
-# path forks and joins its helper stream inside the call), and the one place that spreads arrays over
-# several streams (assemble_sketched_tt) holds them until it has synchronised.
-_SMALL_CAP = 2 << 30
-_small: "dict[int, list]" = {}
-_small_bytes = 0
-
-
-def _small_class(nbytes: int) -> int:
+def _size_class(nbytes: int) -> int:
+    if nbytes >= _POOL_MIN:
+        return (int(nbytes) + (2 << 20) - 1) & ~((2 << 20) - 1)
     n = 256
     while n < nbytes:
         n <<= 1
     return n
 
 
+def _reusable(tag: dict, stream: int) -> bool:
+    for s, gen in tag.items():
+        if s != stream and not nat.drained_since(s, gen):
+            return False
+    return True
+
+
+def _pool_take(size: int, stream: int):
+    lst = _pool.get(size)
+    if lst:
+        for i in range(len(lst) - 1, max(len(lst) - 1 - _SCAN, -1), -1):
+            if _reusable(lst[i][0], stream):
+                _, ptr = lst.pop(i)
+                _pool_bytes[size >= _POOL_MIN] -= size
+                return ptr
+    return None
+
+
+def _pool_give(size: int, ptr: int) -> None:
+    big = size >= _POOL_MIN
+    cap = _POOL_CAP if big else _SMALL_CAP
+    if not big and _pool_bytes[False] + size > cap:
+        nat.lib().ttsk_free(ctypes.c_void_p(ptr))          # hipFree waits for the device itself
+        return
+    _pool.setdefault(size, []).append((nat.dirty_snapshot(), ptr))
+    _pool_bytes[big] += size
+    while big and _pool_bytes[True] > cap:          # drop the largest class first
+        top = max((k for k, v in _pool.items() if v and k >= _POOL_MIN), default=None)
+        if top is None:
+            break
+        _, old = _pool[top].pop(0)
+        _pool_bytes[True] -= top
+        nat.lib().ttsk_free(ctypes.c_void_p(old))
+
+
 class _Buffer:
-    """Owns one ttsk_malloc allocation (recycled through the pools above)."""
+    """Owns one ttsk_malloc allocation (recycled through the pool above)."""
     __slots__ = ("ptr", "nbytes", "_pooled")
 
-    def __init__(self, nbytes: int):
-        global _small_bytes
+    def __init__(self, nbytes: int, stream: int = 0):
         self.nbytes = int(nbytes)
-        if self.nbytes >= _POOL_MIN:
-            self._pooled = _pool_round(self.nbytes)
-            got = _pool_take(self._pooled)
-        else:
-            self._pooled = _small_class(self.nbytes)
-            lst = _small.get(self._pooled)
-            got = lst.pop() if lst else None
-            if got is not None:
-                _small_bytes -= self._pooled
+        self._pooled = _size_class(self.nbytes)
+        got = _pool_take(self._pooled, int(stream))
         if got is not None:
             self.ptr = got
             return
@@ -105,16 +103,9 @@ class _Buffer:
         self.ptr = p.value
 
     def __del__(self):
-        global _small_bytes
         try:
             if self.ptr:
-                if self.nbytes >= _POOL_MIN:
-                    _pool_give(self._pooled, self.ptr)
-                elif _small_bytes + self._pooled <= _SMALL_CAP:
-                    _small.setdefault(self._pooled, []).append(self.ptr)
-                    _small_bytes += self._pooled
-                else:
-                    nat.lib().ttsk_free(ctypes.c_void_p(self.ptr))
+                _pool_give(self._pooled, self.ptr)
         except Exception:  # interpreter shutdown
             pass
         self.ptr = None
@@ -142,14 +133,15 @@ class DevArray:
 
     # ---- construction
     @classmethod
-    def empty(cls, shape, dtype=_F64) -> "DevArray":
+    def empty(cls, shape, dtype=_F64, stream=0) -> "DevArray":
+        """``stream``: the library stream that touches the array first (see the pool note above)."""
         shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
         n = int(np.prod(shape, dtype=np.int64))
-        return cls(_Buffer(n * np.dtype(dtype).itemsize), 0, shape, _c_strides(shape), dtype)
+        return cls(_Buffer(n * np.dtype(dtype).itemsize, stream), 0, shape, _c_strides(shape), dtype)
 
     @classmethod
     def zeros(cls, shape, dtype=_F64, stream=0) -> "DevArray":
-        a = cls.empty(shape, dtype)
+        a = cls.empty(shape, dtype, stream)
         if a.size:
             nat.call("ttsk_memset", ctypes.c_void_p(a.ptr), 0, ctypes.c_size_t(a.size * a.dtype.itemsize), stream)
         return a
@@ -159,7 +151,7 @@ class DevArray:
         arr = np.ascontiguousarray(arr, dtype=dtype if dtype is not None else getattr(arr, "dtype", None))
         if arr.dtype not in (np.float64, np.int64, np.uint64):
             arr = arr.astype(np.float64)
-        a = cls.empty(arr.shape, arr.dtype)
+        a = cls.empty(arr.shape, arr.dtype, stream)
         if arr.size:
             nat.call("ttsk_h2d", ctypes.c_void_p(a.ptr), ctypes.c_void_p(arr.ctypes.data),
                      ctypes.c_size_t(arr.nbytes), stream)
@@ -260,12 +252,12 @@ class DevArray:
             return self
         if self.dtype != _F64:
             raise ValueError("strided copies are implemented for fp64 only")
-        out = DevArray.empty(self.shape, self.dtype)
+        out = DevArray.empty(self.shape, self.dtype, stream)
         copy_into(out, self, stream)
         return out
 
     def copy(self, stream=0) -> "DevArray":
-        out = DevArray.empty(self.shape, self.dtype)
+        out = DevArray.empty(self.shape, self.dtype, stream)
         if self.size:
             if self.is_contiguous():
                 nat.call("ttsk_d2d", ctypes.c_void_p(out.ptr), ctypes.c_void_p(self.ptr),
@@ -409,7 +401,7 @@ def contract(spec: str, A: DevArray, B: DevArray, out: Optional[DevArray] = None
                 raise ValueError(f"contract {spec}: extent mismatch on '{c}'")
     out_shape = tuple(size[c] for c in co)
     if out is None:
-        out = DevArray.empty(out_shape)
+        out = DevArray.empty(out_shape, stream=stream)
         accumulate = False
     elif out.shape != out_shape:
         raise ValueError(f"contract {spec}: out has shape {out.shape}, expected {out_shape}")

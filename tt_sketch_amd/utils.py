@@ -82,7 +82,7 @@ def pinv_dev(Omega, rcond=None, stream=0) -> DevArray:
     dropped, rcond = eps when None) -- the factorisation behind utils.py:98-109."""
     Om = as_dev(Omega, stream).contiguous(stream)
     l, r = Om.shape
-    P = DevArray.empty((r, l))
+    P = DevArray.empty((r, l), stream=stream)
     nat.call("ttsk_pinv", ctypes.c_void_p(Om.ptr), l, r, -1.0 if rcond is None else float(rcond),
              ctypes.c_void_p(P.ptr), None, stream)
     return P
@@ -98,7 +98,7 @@ def pinv_dev_many(Omegas, rcond=None, streams=None):
         group = []
         for k, st in zip(range(lo, min(lo + len(streams), len(Omegas))), streams):
             Om = as_dev(Omegas[k], st).contiguous(st)
-            P = DevArray.empty((Om.shape[1], Om.shape[0]))
+            P = DevArray.empty((Om.shape[1], Om.shape[0]), stream=st)
             nat.call("ttsk_pinv_begin", ctypes.c_void_p(Om.ptr), Om.shape[0], Om.shape[1], rc, ctypes.c_void_p(P.ptr), st)
             group.append((k, st, Om, P))
         for k, st, Om, P in group:
@@ -128,7 +128,7 @@ def random_normal_dev(shape, seed=None, scale: float = 1.0, stream=0) -> DevArra
     element index).  Stands in for utils.py:178-227, whose stream is host dependent."""
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
-    out = DevArray.empty(shape)
+    out = DevArray.empty(shape, stream=stream)
     nat.call("ttsk_fill_normal", ctypes.c_void_p(out.ptr), ctypes.c_size_t(out.size),
              ctypes.c_uint64(int(seed) % 2**64), float(scale), stream)
     return out
