@@ -128,3 +128,151 @@ def test_c5_tensor_sum_full_size(tsa):
     t_cpu = time.perf_counter() - t0
     _check(stt.sketch_, oP, oO)
     print(f"\n[C5] gpu {t_gpu * 1e3:.1f} ms (incl. D2H of the sketch), oracle {t_cpu * 1e3:.0f} ms")
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE sizes on the HIP path with a real check: the kernel variants that
+# only run at these sizes (64-bit origins of the streamed kernel, rebased long-K row tiles) were timed
+# in round 1 but never compared with anything.
+# ---------------------------------------------------------------------------------------------------
+def _dense_of_tt_on_device(tsa, cores):
+    """full(cores) built in HBM (never on the host): 64^5 doubles = 8.6 GB at C2."""
+    from tt_sketch_amd.device import DevArray, contract
+    P = DevArray.from_host(cores[0].reshape(cores[0].shape[1], -1))
+    for c in cores[1:]:
+        P = contract("ia,ajb->ijb", P, DevArray.from_host(c))
+        P = P.reshape(-1, P.shape[-1])
+    return P.reshape(tuple(c.shape[1] for c in cores))
+
+
+def _check_lists(got, want, tol, what):
+    for k, (a, b) in enumerate(zip(got, want)):
+        a = np.asarray(a)
+        assert a.shape == b.shape, (what, k, a.shape, b.shape)
+        assert rel(a, b) < tol, (what, k, a.shape, rel(a, b))
+
+
+def test_c2_dense_full_size(tsa):
+    """configs[1] at FULL size: dense d=5 n=64 (8.59 GB), TensorTrainDRM l=20 r=40.  X is the full form
+    of a rank-3 TT, built on the device; the expected sketch of the dense path (incl. the reversed-mode
+    quirk of the right matrices) then factors through small matrices (tests/structured.py, pinned to the
+    oracle's dense path by test_oracle_golden.py).  Plus linearity over the two half slabs of mode 0."""
+    from tests import structured as st
+    from tt_sketch_amd.device import DevArray, sync
+    from tt_sketch_amd import _native as nat
+    import ctypes
+    rng = np.random.default_rng(2)
+    d, n, s, l, r = 5, 64, 3, 20, 40
+    shape = (n,) * d
+    cores = [c * 8.0 for c in orc.random_tt(shape, s, rng)]           # entries of X of order 1
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left = tsa.TensorTrainDRM(l, shape, False, seed=1, cores=ld.cores)
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=rd.cores)
+    X = _dense_of_tt_on_device(tsa, cores)
+    assert X.size * 8 == 8 * 64 ** 5 and X.is_contiguous()
+    # spot check of the device-built tensor against the TT
+    probe = X[17, 5, 63, 0].get()                                       # (64,) fibre of the last mode
+    want = (cores[0][0, 17] @ cores[1][:, 5] @ cores[2][:, 63] @ cores[3][:, 0]) @ cores[4][:, :, 0]
+    assert probe.shape == (64,) and rel(probe, want) < 1e-13
+    T = tsa.DenseTensor(X)
+    t0 = time.perf_counter()
+    sk = tsa.general_sketch(T, left, right, tsa.SketchMethod.streaming)
+    sync()
+    t_gpu = time.perf_counter() - t0
+    sP, sO = st.dense_sketch_of_tt_ttdrm(cores, ld.cores, rd.cores)
+    _check_lists(sk.Psi_cores + sk.Omega_mats, sP + sO, 1e-11, "C2 TT-DRM")
+    # linearity: sketch(X) = sketch(X with the upper half of mode 0 zeroed) + sketch(the rest)
+    half = X.size // 2
+    parts = []
+    for lo in (0, half):
+        Y = X.copy()
+        nat.call("ttsk_memset", ctypes.c_void_p(Y.ptr + 8 * (half - lo)), 0, ctypes.c_size_t(8 * half), 0)
+        parts.append(tsa.general_sketch(tsa.DenseTensor(Y), left, right, tsa.SketchMethod.streaming))
+        del Y
+    tot = parts[0] + parts[1]
+    _check_lists(tot.Psi_cores + tot.Omega_mats, sk.Psi_cores + sk.Omega_mats, 1e-11, "C2 linearity")
+    print(f"\n[C2 full size, TT-DRM] dense sketch of 8.59 GB: {t_gpu * 1e3:.1f} ms (first call)")
+
+
+def test_c2_dense_full_size_gaussian_drm(tsa):
+    """The same tensor with device-sampled DenseGaussianDRMs l=20 r=40 (8.2 GB of Gaussian matrices: the
+    k-contiguous generic-tile variants of the long-K kernel).  The matrices are read back and the
+    expected sketch is formed on the host through the TT's partial products."""
+    from tests import structured as st
+    from tt_sketch_amd.device import sync
+    rng = np.random.default_rng(12)
+    d, n, s, l, r = 5, 64, 3, 20, 40
+    shape = (n,) * d
+    cores = [c * 8.0 for c in orc.random_tt(shape, s, rng)]
+    X = _dense_of_tt_on_device(tsa, cores)
+    left = tsa.DenseGaussianDRM(l, shape, False, seed=41)
+    right = tsa.DenseGaussianDRM(r, shape, True, seed=42)
+    sk = tsa.general_sketch(tsa.DenseTensor(X), left, right, tsa.SketchMethod.streaming)
+    sync()
+    A = [np.asarray(m) for m in left.sketching_mats]                 # (l, n^{mu+1})
+    B = [np.asarray(m) for m in right.sketching_mats][::-1]          # user order: B[mu] (r, n^{d-1-mu})
+    assert A[3].shape == (l, n ** 4) and B[0].shape == (r, n ** 4)
+    sP, sO = st.dense_sketch_of_tt_matrices(cores, A, B)
+    _check_lists(sk.Psi_cores + sk.Omega_mats, sP + sO, 1e-11, "C2 dense-Gaussian DRM")
+
+
+def test_c4_sparse_full_size(tsa):
+    """configs[3] at FULL size: nnz = 10^7, shape (200,150,100,120,300), SparseGaussianDRM l=10 r=15.
+    sketch(whole) == sketch(first 10^5 nonzeros) + sketch(the rest); the 10^5 part against the oracle."""
+    shape = (200, 150, 100, 120, 300)
+    rng = np.random.default_rng(44)
+    nnz, small = 10_000_000, 100_000
+    idx = np.stack([rng.integers(0, n, nnz) for n in shape]).astype(np.int64)
+    val = rng.standard_normal(nnz)
+    ld = tsa.SparseGaussianDRM(10, shape, False, seed=3)
+    rd = tsa.SparseGaussianDRM(15, shape, True, seed=4)
+    T = tsa.SparseTensor(shape, idx, val)
+    t0 = time.perf_counter()
+    whole = tsa.general_sketch(T, ld, rd, tsa.SketchMethod.streaming)
+    wP, wO = whole.Psi_cores, whole.Omega_mats
+    t_gpu = time.perf_counter() - t0
+    a = tsa.general_sketch(tsa.SparseTensor(shape, idx[:, :small], val[:small]), ld, rd, tsa.SketchMethod.streaming)
+    b = tsa.general_sketch(tsa.SparseTensor(shape, idx[:, small:], val[small:]), ld, rd, tsa.SketchMethod.streaming)
+    tot = a + b
+    _check_lists(tot.Psi_cores + tot.Omega_mats, wP + wO, 1e-11, "C4 shards")
+    old = orc.HashGaussDrm(3, shape, False, (0,) * 4, (10,) * 4)
+    ord_ = orc.HashGaussDrm(4, shape, True, (0,) * 4, (15,) * 4)
+    oP, oO = orc.general_sketch("sparse", (shape, idx[:, :small], val[:small]), old, ord_, "streaming")
+    _check_lists(a.Psi_cores + a.Omega_mats, oP + oO, 1e-11, "C4 10^5 part vs oracle")
+    # a checksum the domain offers: sum_j Psi_mu[:, j, :] = (L_{mu-1} * entries) R_mu^T needs no mode split;
+    # for mu = d-1 and mu = 0 that is the sum over all nonzeros of the other side's panel
+    assert abs(wP[-1].sum() - sum(p.sum() for p in (a.Psi_cores[-1], b.Psi_cores[-1]))) < 1e-9 * np.abs(wP[-1]).sum()
+    print(f"\n[C4 full size] nnz=1e7 sketch {t_gpu * 1e3:.0f} ms (incl. H2D of 480 MB and D2H of the sketch)")
+
+
+def test_c3_batch16_every_tensor_vs_oracle(tsa):
+    """The bench's own pass -- 16 TTs of the C3 signature in ONE ttsk_tt_sketch_batch -- with every one of
+    the 16 sketches compared with the oracle (bench.py checks tensors 0 and 15 only)."""
+    import ctypes
+    from tt_sketch_amd import tt_fused
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(33)
+    shape, nb = (200,) * 6, 16
+    ld, rd = orc.random_tt_drm(shape, 50, False, rng), orc.random_tt_drm(shape, 100, True, rng)
+    left = tsa.TensorTrainDRM(50, shape, False, seed=1, cores=ld.cores)
+    right = tsa.TensorTrainDRM(100, shape, True, seed=2, cores=rd.cores)
+    tts = [orc.random_tt(shape, 100, rng) for _ in range(nb)]
+    dev = [tsa.TensorTrain(c) for c in tts]
+    plan = tt_fused.TTSketchPlan(dev[0].shape, dev[0].rank, left, right)
+    keep, flat = [], []
+    for t in dev:
+        ptrs, k = plan.core_pointers(t)
+        keep.append(k)
+        flat += [ptrs[i] for i in range(plan.d)]
+    stride = plan.size + (plan.size & 1)
+    out = DevArray.zeros((nb * stride,))
+    plan.run_batch((ctypes.c_void_p * len(flat))(*flat), nb, out, stride)
+    worst = 0.0
+    for b, cores in enumerate(tts):
+        oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
+        Psi, Om = plan.views(out[b * stride:b * stride + plan.size])
+        for a, c in zip(Psi + Om, oP + oO):
+            e = rel(a.get(), c)
+            worst = max(worst, e)
+            assert e < TOL, (b, a.shape, e)
+    print(f"\n[C3 batch 16] worst relative error over 16 x 11 arrays: {worst:.2e}")

@@ -139,3 +139,33 @@ def test_gmres_oracle_matches_reference_run(method, use_pre):
     assert np.array_equal(np.array(hist["rank"]), z[key + "_rank"])
     assert np.allclose(hist["H_matrix"], z[key + "_H"], rtol=1e-6, atol=1e-9)
     assert rel(orc.tt_to_numpy(x), z[key + "_x"]) < 1e-8
+
+
+def test_structured_dense_formulas_equal_the_oracle_dense_path():
+    """tests/structured.py (the checker of the full-size dense GPU test) against the oracle's dense path,
+    incl. the reversed-mode quirk of the right TensorTrainDRM matrices."""
+    from tests import structured as st
+    rng = np.random.default_rng(11)
+    for d, n, s, l, r in ((5, 4, 3, 5, 7), (4, 6, 2, 3, 4), (3, 5, 2, 4, 6)):
+        shape = (n,) * d
+        cores = orc.random_tt(shape, s, rng)
+        X = orc.tt_to_numpy(cores)
+        ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+        oP, oO = orc.general_sketch("dense", X, ld, rd, "streaming")
+        sP, sO = st.dense_sketch_of_tt_ttdrm(cores, ld.cores, rd.cores)
+        for a, b in zip(sP + sO, oP + oO):
+            assert a.shape == b.shape and rel(a, b) < 1e-12, (d, a.shape, rel(a, b))
+        # explicit matrices (DenseGaussianDRM): right matrices sampled on the reversed shape
+        A, cols = [], 1
+        for mu in range(d - 1):
+            cols *= n
+            A.append(rng.standard_normal((l, cols)))
+        Bw, cols = [], 1
+        for mu in range(d - 1):
+            cols *= n
+            Bw.append(rng.standard_normal((r, cols)))           # walking order: mats[j] covers modes d-1..d-1-j
+        dl, dr = orc.DenseDrm(A, shape, False), orc.DenseDrm(Bw, shape, True)
+        oP, oO = orc.general_sketch("dense", X, dl, dr, "streaming")
+        sP, sO = st.dense_sketch_of_tt_matrices(cores, A, Bw[::-1])
+        for a, b in zip(sP + sO, oP + oO):
+            assert a.shape == b.shape and rel(a, b) < 1e-12, (d, a.shape, rel(a, b))

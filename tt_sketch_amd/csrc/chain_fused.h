@@ -1,0 +1,277 @@
+// One step of a TensorTrainDRM chain with the intermediate kept on chip.
+//
+//   reference: tensor_train_drm.py:81-87   L_mu[l,m] = sum_{i,j,k} L_{mu-1}[i,j] X_mu[i,k,l] D_mu[j,k,m]
+//   (right sketches run the same line on the transposed tensor, drm_base.py:122-145)
+//
+// In the names used here, for one tensor of the batch and one mode:
+//   W [c][a]      the carried matrix L_{mu-1} / R  (K1 x A), c = TT bond contracted with X, a = DRM rank in
+//   X             the TT core, addressed by strides as G_k[j][c] (k = mode index, j = the other TT bond)
+//   E [a][k][a']  the DRM core (A x n x A2), shared by all tensors of the batch
+//   Out[j][a']    = sum_k ( G_k W ) E_k          (J x A2)
+// The two-launch form (skinny.h) writes T[a][k][j] = sum_c W[c][a] G_k[j][c] to HBM and reads it back
+// for the second product: ~55 % of the bytes a chain step moves.  Here a workgroup owns a range of
+// slices k of one tensor; per slice
+//   phase A   T_k^T[a][j] = sum_c W[c][a] G_k[j][c]      W from LDS, G_k fragments straight from memory
+//   phase B   Out[j][a'] += sum_a T_k[j][a] E_k[a][a']   E_k from LDS
+// and T_k never leaves the registers: with mfma(A = W^T fragment, B = G fragment) register t of the
+// 16x16 accumulator tile Q holds T^T[16 Q + 4 t + (lane >> 4)][lane & 15], which IS the A-operand
+// fragment of k-block 4 Q + t for phase B (lane (x, kq) holds T[j0 + x][4 (4 Q + t) + kq]).
+// Wave w owns the 16 rows j0 = 16 w of the output; a further wave does nothing but bring E_k into LDS
+// (global_load_lds, 1 KB per instruction) while the others are in phase A.  The left chain also needs
+// T in memory for Psi_mu = T_mu R_mu (tensor_train_sketch.py:28-34): it is stored from the phase-A
+// registers on the way (WT).
+//
+// Partial tiles (rank 100 = 6 x 16 + 4, rank 50 = 3 x 16 + 2) are 4-wide strips computed with
+// v_mfma_f64_4x4x4 (4 blocks): 16 instead of 64 cycles of the matrix pipe.
+#pragma once
+#include "skinny.h"
+
+namespace ttsk {
+
+struct ChainStep {
+    const double *W[SK_MAXB];
+    const double *X[SK_MAXB];
+    double *T[SK_MAXB];          // WT: T[a][k][j] (A x n x J contiguous)
+    const double *E;
+    double *slab;                // [problem][workgroup of the problem][J][A2]
+    int nb, wpp, n;              // problems, workgroups per problem, slices (mode size)
+    int K1, A, A2, J;
+    int64_t w_c;                 // row stride of W (elements); columns contiguous
+    int64_t x_j, x_k, x_c;       // element strides of X
+    int64_t x_extent, t_extent;  // elements addressable from the bases
+    int AP, A2P;                 // padded extents of the two LDS images
+    int ebase;                   // offset (doubles) of the E image in LDS
+    int eunits;                  // 16-byte units of the E image the loader fills (multiple of 64)
+    int xcd_map;                 // 1: workgroups of the same slice range share an XCD (E_k from one L2)
+};
+
+constexpr int CF_MAX_DMA = 80;   // loader instructions per slice (80 KB of LDS / 1 KB)
+
+__device__ __forceinline__ void cf_barrier()
+{
+    // LDS traffic of this wave is complete, nothing moves across; vector-memory loads stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NQF / NNF full 16-wide tiles of a / a', STRQ / STRN 4-wide strips behind them; D ring depth of the
+// G fragments; WT: T is also written to memory; OCC workgroups per CU the register budget allows.
+template <int NQF, int STRQ, int NNF, int STRN, int D, bool WT, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
+{
+    extern __shared__ double cf_lds[];
+    double *Wl = cf_lds;
+    double *El = cf_lds + a.ebase;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int x16 = lane & 15, kq = lane >> 4;
+    int prob, g;
+    if (a.xcd_map) {
+        // blocks b and b + 8 share an XCD: deal the slice ranges g over the XCDs, all problems of a
+        // range to the same one (they read the same E_k)
+        const int gpx = a.wpp >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        g = xcd * gpx + j % gpx;
+        prob = j / gpx;
+    } else {
+        prob = blockIdx.x / a.wpp;
+        g = blockIdx.x - prob * a.wpp;
+    }
+    const int k_beg = (int)((int64_t)g * a.n / a.wpp), k_end = (int)((int64_t)(g + 1) * a.n / a.wpp);
+    const int NW = (a.J + 15) >> 4;
+    const int KB1 = (a.K1 + 3) >> 2;
+    const int AP = a.AP, A2P = a.A2P;
+
+    // ---- stage W: Wl[(c >> 1) * 2 AP + 2 a + (c & 1)], zero beyond (K1, A).  A pair of k rows interleaved:
+    // the 32 lanes (kq in {0, 1}, x) of a fragment read 32 consecutive doubles = all 64 banks once.
+    {
+        const double *Wp = uniform_ptr(a.W[prob]);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, ((int64_t)(a.K1 - 1) * a.w_c + a.A) * 8);
+        const int total = 4 * KB1 * AP;
+        constexpr int BATCH = 10;
+        for (int e0 = tid; e0 < total; e0 += 512 * BATCH) {
+            double v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int c = e / AP, col = e - c * AP;
+                v[u] = ld8(rw, (e < total && c < a.K1 && col < a.A) ? (uint32_t)(((int64_t)c * a.w_c + col) * 8) : OOB_OFF, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int c = e / AP, col = e - c * AP;
+                if (e < total) Wl[(c >> 1) * 2 * AP + 2 * col + (c & 1)] = v[u];
+            }
+        }
+    }
+
+    if (w == 7) {
+        // ---- loader: E_k -> El in 16-byte units.  Unit u of section sec (rows 2 sec, 2 sec + 1) is
+        // columns (2 (u >> 1), + 1) of row 2 sec + (u & 1); lanes (kq in {0, 1}, x) of a fragment read 16
+        // consecutive units.  Rows beyond A repeat row A - 1: they meet exact zeros of T.
+        const double *Ep = a.E;
+        const int NI = a.eunits >> 6;
+        uint32_t eoff[CF_MAX_DMA];
+#pragma unroll
+        for (int m = 0; m < CF_MAX_DMA; ++m) {
+            const int U = 64 * m + lane;
+            const int sec = U / A2P, u = U - sec * A2P;
+            int row = 2 * sec + (u & 1);
+            row = row < a.A ? row : a.A - 1;
+            int col = 2 * (u >> 1);
+            col = col + 1 < a.A2 ? col : 0;
+            eoff[m] = (uint32_t)((int64_t)row * a.n * a.A2 + col);
+        }
+        __syncthreads();                               // W staged (all waves)
+        for (int k = k_beg; k < k_end; ++k) {
+            const double *Ek = Ep + (int64_t)k * a.A2;
+#pragma unroll
+            for (int m = 0; m < CF_MAX_DMA; ++m) {
+                if (m < NI)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ek + eoff[m]),
+                                                     (__attribute__((address_space(3))) void *)(El + m * 128), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cf_barrier();                              // B1: E_k is in LDS, phase A of slice k is done
+            cf_barrier();                              // B2: phase B of slice k is done, El may be overwritten
+        }
+        return;
+    }
+    __syncthreads();                                   // W staged
+    if (w >= NW) return;                               // no rows for this wave (a finished wave leaves the barrier count)
+
+    // ---- compute wave: rows j0 .. j0 + 15 of the output
+    const int j0 = 16 * w;
+    const bool jok = j0 + x16 < a.J;
+    const uint32_t xlane = jok ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
+    const int nkb_lane = a.K1 > kq ? (a.K1 - kq + 3) >> 2 : 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(uniform_ptr(a.X[prob]), a.x_extent * 8);
+    const uint32_t xstep = (uint32_t)(4 * a.x_c * 8), kstep = (uint32_t)(a.x_k * 8);
+    const int ITER = (KB1 + D - 1) / D, KBP = ITER * D;
+    auto xload = [&](int k, int kb) -> double {
+        return ld8(rx, (kb < nkb_lane && k < k_end) ? xlane : OOB_OFF, (uint32_t)k * kstep + (uint32_t)kb * xstep);
+    };
+    double ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = xload(k_beg, d);
+
+    v4d acc2[NNF ? NNF : 1];
+    double acc2s[STRN ? STRN : 1];
+#pragma unroll
+    for (int p = 0; p < NNF; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[p][t] = 0.0;
+#pragma unroll
+    for (int q = 0; q < STRN; ++q) acc2s[q] = 0.0;
+
+    // LDS addresses of this lane's fragment elements inside a k-block's two sections
+    const int wl_lane = (kq >> 1) * 2 * AP + 2 * x16 + (kq & 1);
+    const int ws_lane = (kq >> 1) * 2 * AP + 2 * (16 * NQF + (x16 & 3)) + (kq & 1);
+    const int el_lane = (kq >> 1) * 2 * A2P + 4 * (x16 >> 1) + 2 * (kq & 1) + (x16 & 1);
+    const int es_col = 16 * NNF + (x16 & 3);
+    const int es_lane = (kq >> 1) * 2 * A2P + 2 * (kq & 1);
+
+    __amdgpu_buffer_rsrc_t rt;
+    if constexpr (WT) rt = make_rsrc(uniform_ptr(a.T[prob]), a.t_extent * 8);
+
+    for (int k = k_beg; k < k_end; ++k) {
+        v4d acc1[NQF ? NQF : 1];
+        double acc1s[STRQ ? STRQ : 1];
+#pragma unroll
+        for (int p = 0; p < NQF; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc1[p][t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < STRQ; ++q) acc1s[q] = 0.0;
+
+        // ---- phase A
+        for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kb = it * D + d;
+                const double bf = ring[d];
+                const int kbn = kb + D;
+                ring[d] = kbn < KBP ? xload(k, kbn) : xload(k + 1, kbn - KBP);
+                if (kb < KB1) {
+                    const double *wk = Wl + kb * 4 * AP;
+                    double af[NQF ? NQF : 1], sf[STRQ ? STRQ : 1];
+#pragma unroll
+                    for (int p = 0; p < NQF; ++p) af[p] = wk[wl_lane + 32 * p];
+#pragma unroll
+                    for (int q = 0; q < STRQ; ++q) sf[q] = wk[ws_lane + 8 * q];
+#pragma unroll
+                    for (int p = 0; p < NQF; ++p) acc1[p] = mfma16(af[p], bf, acc1[p]);
+#pragma unroll
+                    for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
+                }
+            }
+        }
+        if constexpr (WT) {
+            // T[a][k][j]: register t of tile p is row a = 16 p + 4 t + kq, 16 consecutive j per row
+            const int64_t nJ = (int64_t)a.n * a.J;
+            const uint32_t tl = jok ? (uint32_t)(((int64_t)kq * nJ + (int64_t)k * a.J + j0 + x16) * 8) : OOB_OFF;
+#pragma unroll
+            for (int p = 0; p < NQF; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    st8(rt, (jok && 16 * p + 4 * t + kq < a.A) ? tl + (uint32_t)((16 * p + 4 * t) * nJ * 8) : OOB_OFF, acc1[p][t]);
+#pragma unroll
+            for (int q = 0; q < STRQ; ++q)
+                st8(rt, (jok && 16 * NQF + 4 * q + kq < a.A) ? tl + (uint32_t)((16 * NQF + 4 * q) * nJ * 8) : OOB_OFF, acc1s[q]);
+        }
+        cf_barrier();                                  // B1
+
+        // ---- phase B: k-block kap = 4 p + t of T is register t of tile p
+#pragma unroll
+        for (int p = 0; p < NQF + (STRQ ? 1 : 0); ++p) {
+#pragma unroll
+            for (int t = 0; t < (p < NQF ? 4 : STRQ); ++t) {
+                const int kap = 4 * p + t;
+                const double af = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
+                const double *ek = El + kap * 4 * A2P;
+                double bf[NNF ? NNF : 1], bs[STRN ? STRN : 1];
+#pragma unroll
+                for (int nn = 0; nn < NNF; ++nn) bf[nn] = ek[el_lane + 32 * nn];
+#pragma unroll
+                for (int q = 0; q < STRN; ++q) {
+                    const int col = es_col + 4 * q;
+                    bs[q] = ek[es_lane + 4 * (col >> 1) + (col & 1)];
+                }
+#pragma unroll
+                for (int nn = 0; nn < NNF; ++nn) acc2[nn] = mfma16(af, bf[nn], acc2[nn]);
+#pragma unroll
+                for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af, bs[q], acc2s[q]);
+            }
+        }
+        cf_barrier();                                  // B2
+    }
+
+    // ---- partial result of this workgroup: slab[problem][g][j][a']
+    double *slab = a.slab + ((int64_t)prob * a.wpp + g) * a.J * a.A2;
+#pragma unroll
+    for (int nn = 0; nn < NNF; ++nn)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + 4 * t + kq, col = 16 * nn + x16;
+            if (j < a.J && col < a.A2) slab[(int64_t)j * a.A2 + col] = acc2[nn][t];
+        }
+#pragma unroll
+    for (int q = 0; q < STRN; ++q) {
+        // 4x4x4 result: lane (i = l >> 4, beta = (l >> 2) & 3, c = l & 3) holds row 4 beta + i, column c of the strip
+        const int j = j0 + 4 * ((lane >> 2) & 3) + kq, col = 16 * NNF + 4 * q + (lane & 3);
+        if (j < a.J && col < a.A2) slab[(int64_t)j * a.A2 + col] = acc2s[q];
+    }
+}
+
+// 1 = launched (the slab reduce included), 0 = shape not covered, < 0 = error
+struct ChainStepArgs {
+    int nb, n, K1, A, A2, J;
+    const double *const *W;      // nb carried matrices (K1 x A), row stride w_c
+    int64_t w_c;
+    const double *const *X;      // nb cores
+    int64_t x_j, x_k, x_c, x_extent;
+    const double *E;             // (A, n, A2) contiguous
+    double *const *T;            // nullptr, or nb buffers (A, n, J) contiguous
+    double *const *Out;          // nb results (J x A2) contiguous
+};
+int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st);
+
+}  // namespace ttsk

@@ -39,19 +39,19 @@ class TensorTrainDRM(CansketchSparse, CansketchTT, CansketchCP, CanSlice, Canske
                 for mu in range(len(walk) - 1)
             ]
         self._dev: List[DevArray] = []
-        self._dev_ids: List[int] = []
+        self._dev_src: list = []          # the host objects the device copies were made from
 
     def dev_cores(self) -> List[DevArray]:
         """Device copies of ``self.cores`` (the list may grow: OrthogTTDRM appends)."""
         for k, c in enumerate(self.cores):
-            if k < len(self._dev) and self._dev_ids[k] == id(c):
+            if k < len(self._dev) and self._dev_src[k] is c:
                 continue
             d = as_dev(c)
             if k < len(self._dev):
-                self._dev[k], self._dev_ids[k] = d, id(c)
+                self._dev[k], self._dev_src[k] = d, c
             else:
                 self._dev.append(d)
-                self._dev_ids.append(id(c))
+                self._dev_src.append(c)
         return self._dev
 
     def _core(self, mu) -> DevArray:

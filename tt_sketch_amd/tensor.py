@@ -32,6 +32,12 @@ def _host(a) -> np.ndarray:
     return a.get() if isinstance(a, DevArray) else np.asarray(a)
 
 
+def _same_objects(key, items) -> bool:
+    """The cached device copies belong to exactly these payload objects (identity, not id(): the id of
+    a collected array can be handed to a new one)."""
+    return key is not None and len(key) == len(items) and all(a is b for a, b in zip(key, items))
+
+
 class Tensor(abc.ABC):
     """Base class: shape, transpose, conversion and the lazy-sum arithmetic."""
 
@@ -126,13 +132,15 @@ class DenseTensor(Tensor):
     """Full ndarray (reference tensor.py:140-182)."""
 
     def __init__(self, data, _dev: Optional[DevArray] = None) -> None:
-        self.data = data
+        self.data = data                  # ndarray, or a DevArray for a tensor built on the device
         self.shape = tuple(data.shape)
         self._dev = _dev
+        self._dev_src = data if _dev is not None else None
 
     def dev_data(self) -> DevArray:
-        if self._dev is None:
+        if self._dev is None or self._dev_src is not self.data:    # `.data` was replaced: upload again
             self._dev = as_dev(self.data)
+            self._dev_src = self.data
         return self._dev
 
     prepare_device = dev_data
@@ -140,8 +148,10 @@ class DenseTensor(Tensor):
     @property
     def T(self) -> "DenseTensor":
         axes = tuple(reversed(range(len(self.shape))))
-        return DenseTensor(np.transpose(self.data, axes),
-                           None if self._dev is None else self._dev.transpose(axes))
+        if isinstance(self.data, DevArray):
+            return DenseTensor(self.data.transpose(axes))
+        cur = self._dev is not None and self._dev_src is self.data
+        return DenseTensor(np.transpose(self.data, axes), self._dev.transpose(axes) if cur else None)
 
     @property
     def size(self) -> int:
@@ -290,13 +300,12 @@ class TensorTrain(Tensor):
         self.shape = tuple(int(C.shape[1]) for C in cores)
         self.rank = tuple(int(C.shape[0]) for C in cores[1:])
         self._dev = _dev
-        self._dev_key = None if _dev is None else tuple(id(c) for c in cores)
+        self._dev_key = None if _dev is None else tuple(cores)      # the objects, compared with `is`
 
     def dev_cores(self) -> List[DevArray]:
-        key = tuple(id(c) for c in self.cores)
-        if self._dev is None or self._dev_key != key:
+        if self._dev is None or not _same_objects(self._dev_key, self.cores):
             self._dev = [as_dev(c) for c in self.cores]
-            self._dev_key = key
+            self._dev_key = tuple(self.cores)
         return self._dev
 
     prepare_device = dev_cores
@@ -307,7 +316,7 @@ class TensorTrain(Tensor):
         cores = [c.transpose(flip) if isinstance(c, DevArray) else np.transpose(c, flip)
                  for c in self.cores[::-1]]
         dev = None
-        if self._dev is not None and self._dev_key == tuple(id(c) for c in self.cores):
+        if self._dev is not None and _same_objects(self._dev_key, self.cores):
             dev = [c.transpose(flip) for c in self._dev[::-1]]
         return TensorTrain(cores, dev)
 
@@ -371,6 +380,7 @@ class TensorTrain(Tensor):
 
     def __setitem__(self, k: int, data) -> None:
         self.cores[k] = data
+        self.invalidate_device()
 
     def gather(self, idx) -> npt.NDArray:
         """Entries at the given multi-indices (rows of ``idx`` are modes)."""
@@ -674,13 +684,12 @@ class CPTensor(Tensor):
         self.rank = int(cores[0].shape[1])
         self.shape = tuple(int(C.shape[0]) for C in cores)
         self._dev = _dev
-        self._dev_key = None if _dev is None else tuple(id(c) for c in cores)
+        self._dev_key = None if _dev is None else tuple(cores)      # the objects, compared with `is`
 
     def dev_cores(self) -> List[DevArray]:
-        key = tuple(id(c) for c in self.cores)
-        if self._dev is None or self._dev_key != key:
+        if self._dev is None or not _same_objects(self._dev_key, self.cores):
             self._dev = [as_dev(c) for c in self.cores]
-            self._dev_key = key
+            self._dev_key = tuple(self.cores)
         return self._dev
 
     prepare_device = dev_cores
@@ -692,7 +701,7 @@ class CPTensor(Tensor):
     @property
     def T(self) -> "CPTensor":
         dev = None
-        if self._dev is not None and self._dev_key == tuple(id(c) for c in self.cores):
+        if self._dev is not None and _same_objects(self._dev_key, self.cores):
             dev = self._dev[::-1]
         return CPTensor(self.cores[::-1], dev)
 
@@ -713,6 +722,7 @@ class CPTensor(Tensor):
 
     def __setitem__(self, k: int, data) -> None:
         self.cores[k] = data
+        self.invalidate_device()
 
     def gather(self, idx) -> npt.NDArray:
         acc = 1.0

@@ -52,10 +52,10 @@ class MPO(Tensor, TTLinearMap):
         self._dev_key = None
 
     def dev_cores(self) -> List[DevArray]:
-        key = tuple(id(c) for c in self.cores)
-        if self._dev is None or self._dev_key != key:
+        key = self._dev_key
+        if self._dev is None or key is None or len(key) != len(self.cores) or any(a is not b for a, b in zip(key, self.cores)):
             self._dev = [as_dev(c).contiguous() for c in self.cores]
-            self._dev_key = key
+            self._dev_key = tuple(self.cores)
         return self._dev
 
     prepare_device = dev_cores
