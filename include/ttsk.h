@@ -123,6 +123,18 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                          const double *const *X, const double *const *DL, const double *const *DR,
                          double *out, int64_t out_stride, int accumulate, int stream);
+/* One interior step of a TensorTrainDRM chain for nb tensors of one signature, both products in one launch
+ * with the intermediate kept on chip (csrc/chain_fused.h):
+ *   Out_b[j, a'] = sum_{c, a, k} W_b[c, a] X_b(j, k, c) E[a, k, a']        (tensor_train_drm.py:81-87)
+ * W_b (K1 x A, row stride w_c), X_b addressed by element strides (x_j, x_k, x_c) -- so the transposed core of
+ * a right sketch needs no copy --, E (A, n, A2) contiguous, Out_b (J x A2) contiguous.  T != NULL also stores
+ * T_b[a, k, j] = sum_c W_b[c, a] X_b(j, k, c) (A x n x J contiguous), the operand Psi_mu shares with the left
+ * chain (tensor_train_sketch.py:28-34).  TTSK_ERR_UNSUPPORTED when the shape is outside the kernel's cover
+ * (ranks whose 16-tile / 4-strip structure has no instantiation, J > 112, odd A2); ttsk_tt_sketch_batch then
+ * uses the two-launch form. */
+int ttsk_chain_step(int nb, int n, int K1, int A, int A2, int J, const double *const *W, int64_t w_c,
+                    const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
+                    const double *E, double *const *T, double *const *Out, int stream);
 /* number of doubles ttsk_tt_sketch writes to `out` */
 int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
                             const int64_t *r_lo, const int64_t *r_hi);
@@ -135,7 +147,9 @@ int ttsk_prof_enable(int on);
 int ttsk_mfma_f64_peak_probe(double *tflops);
 /* class 0/1: right-chain GEMM1 (T = R^T X^T) / GEMM2 (split-K); 2/3: left-chain GEMM1 / GEMM2;
  * 4: Psi GEMM; 5: small products (Omega, first mode); 7: untagged ttsk_gemm calls.  Only the main
- * contraction kernel of each call is bracketed (not the split-K reduce / zero fill). */
+ * contraction kernel of each call is bracketed (not the split-K reduce / zero fill) -- except for the fused
+ * chain step, which replaces BOTH products of a step: it is filed under class 1 (right) / 3 (left) with the
+ * flops of both and its slab reduce inside the bracket. */
 int ttsk_prof_read(int cls, int64_t *launches, double *total_ms, double *flops);
 /* rocprofv3 name of the contraction-kernel instantiation last launched for class `cls` */
 int ttsk_prof_kernel_name(int cls, char *buf, size_t len);

@@ -808,3 +808,46 @@ def test_bench_collective_path_with_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tts_per_step"] == 4
+
+
+@pytest.mark.parametrize("case", [
+    # (nb, n, K1, A, A2, J, right-chain strides?, T written?)
+    (16, 200, 100, 100, 100, 100, True, False),      # C3 right chain: 6 tiles + 1 strip, 7 waves
+    (16, 200, 100, 50, 50, 100, False, True),        # C3 left chain: 3 tiles + 1 strip (2 of 4 columns valid), T stored
+    (3, 37, 100, 100, 100, 100, True, False),        # few slices, unequal ranges
+    (2, 50, 97, 100, 100, 83, True, True),           # odd K1 and J: masked fragments, partial last wave
+    (5, 64, 64, 52, 50, 33, False, True),            # ranks in one structure (3 tiles + strip), A != A2
+    (1, 30, 100, 98, 100, 100, False, False),        # even / odd padding inside the strip
+])
+def test_fused_chain_step_against_einsum(tsa, case):
+    """ttsk_chain_step (csrc/chain_fused.h): one step of TensorTrainDRM.sketch_tt
+    (tensor_train_drm.py:81-87) with the intermediate on chip == the two einsums, and the optional T."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, sync
+    nb, n, K1, A, A2, J, right, wt = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    W = [rng.standard_normal((K1, A)) for _ in range(nb)]
+    E = rng.standard_normal((A, n, A2))
+    if right:      # X[j][k][c]
+        X = [rng.standard_normal((J, n, K1)) for _ in range(nb)]
+        strides = (n * K1, K1, 1)
+        want_T = [np.einsum("ca,jkc->akj", w, x) for w, x in zip(W, X)]
+    else:          # X[c][k][j]
+        X = [rng.standard_normal((K1, n, J)) for _ in range(nb)]
+        strides = (1, J, n * J)
+        want_T = [np.einsum("ca,ckj->akj", w, x) for w, x in zip(W, X)]
+    want = [np.einsum("akj,akb->jb", t, E) for t in want_T]
+    dW, dX = [DevArray.from_host(w) for w in W], [DevArray.from_host(x) for x in X]
+    dE = DevArray.from_host(E)
+    dO = [DevArray.zeros((J, A2)) for _ in range(nb)]
+    dT = [DevArray.zeros((A, n, J)) for _ in range(nb)] if wt else None
+    P = ctypes.c_void_p
+    arr = lambda xs: (P * nb)(*[x.ptr for x in xs])
+    nat.call("ttsk_chain_step", nb, n, K1, A, A2, J, arr(dW), A, arr(dX), strides[0], strides[1], strides[2],
+             X[0].size, P(dE.ptr), arr(dT) if wt else None, arr(dO), 0)
+    sync()
+    for b in range(nb):
+        assert rel(dO[b].get(), want[b]) < TOL, (b, rel(dO[b].get(), want[b]))
+        if wt:
+            assert rel(dT[b].get(), want_T[b]) < TOL, (b, rel(dT[b].get(), want_T[b]))

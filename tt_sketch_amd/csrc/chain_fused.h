@@ -43,19 +43,23 @@ struct ChainStep {
     int ebase;                   // offset (doubles) of the E image in LDS
     int eunits;                  // 16-byte units of the E image the loader fills (multiple of 64)
     int xcd_map;                 // 1: workgroups of the same slice range share an XCD (E_k from one L2)
+    int diag;                    // timing experiments (TTSK_CF_DIAG): 1 = no X loads, 2 = no E loads, 4 = no barriers; results are then wrong
+    long long *stamps;           // diagnostics (TTSK_CF_STAMPS): s_memtime of workgroup 0, [slice][wave][8]
 };
 
-constexpr int CF_MAX_DMA = 80;   // loader instructions per slice (80 KB of LDS / 1 KB)
+constexpr int CF_MAX_DMA = 160;  // loader instructions per slice (1 KB each)
 
 __device__ __forceinline__ void cf_barrier()
 {
     // LDS traffic of this wave is complete, nothing moves across; vector-memory loads stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#define CF_BARRIER() do { if (!(a.diag & 4)) cf_barrier(); } while (0)
+#define CF_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && lane == 0 && k - k_beg < 8) a.stamps[((k - k_beg) * 8 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // NQF / NNF full 16-wide tiles of a / a', STRQ / STRN 4-wide strips behind them; D ring depth of the
 // G fragments; WT: T is also written to memory; OCC workgroups per CU the register budget allows.
-template <int NQF, int STRQ, int NNF, int STRN, int D, bool WT, int OCC>
+template <int NQF, int STRQ, int NNF, int STRN, int D, bool WT, int OCC, int EBUF, int UNR = 5 * D>
 __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
 {
     extern __shared__ double cf_lds[];
@@ -107,31 +111,54 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         // ---- loader: E_k -> El in 16-byte units.  Unit u of section sec (rows 2 sec, 2 sec + 1) is
         // columns (2 (u >> 1), + 1) of row 2 sec + (u & 1); lanes (kq in {0, 1}, x) of a fragment read 16
         // consecutive units.  Rows beyond A repeat row A - 1: they meet exact zeros of T.
-        const double *Ep = a.E;
-        const int NI = a.eunits >> 6;
-        uint32_t eoff[CF_MAX_DMA];
-#pragma unroll
-        for (int m = 0; m < CF_MAX_DMA; ++m) {
-            const int U = 64 * m + lane;
-            const int sec = U / A2P, u = U - sec * A2P;
-            int row = 2 * sec + (u & 1);
-            row = row < a.A ? row : a.A - 1;
-            int col = 2 * (u >> 1);
-            col = col + 1 < a.A2 ? col : 0;
-            eoff[m] = (uint32_t)((int64_t)row * a.n * a.A2 + col);
-        }
-        __syncthreads();                               // W staged (all waves)
-        for (int k = k_beg; k < k_end; ++k) {
-            const double *Ek = Ep + (int64_t)k * a.A2;
-#pragma unroll
-            for (int m = 0; m < CF_MAX_DMA; ++m) {
-                if (m < NI)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ek + eoff[m]),
-                                                     (__attribute__((address_space(3))) void *)(El + m * 128), 16, 0, 0);
+        // (A rolled loop: unrolled, the 80 LDS destinations are hoisted into 80 scalar registers and the
+        // whole kernel starts spilling them.)
+        const int NI = (a.diag & 2) ? 0 : a.eunits >> 6;
+        const uint32_t inv = (uint32_t)(((1ull << 32) + (uint32_t)A2P - 1) / (uint32_t)A2P);   // U / A2P for U < 2^16
+        const int64_t rowstride = (int64_t)a.n * a.A2;
+        const int ebuf = a.eunits * 2;                 // doubles per E image
+        auto fill = [&](int k) {
+            const double *Ek = a.E + (int64_t)k * a.A2;
+            double *dst = El + (EBUF == 2 ? (k & 1) * ebuf : 0);
+#pragma unroll 2
+            for (int m = 0; m < NI; ++m) {
+                const uint32_t U = 64u * (uint32_t)m + (uint32_t)lane;
+                const uint32_t sec = (uint32_t)(((uint64_t)U * inv) >> 32), u = U - sec * (uint32_t)A2P;
+                int row = (int)(2 * sec + (u & 1));
+                row = row < a.A ? row : a.A - 1;
+                int col = (int)(2 * (u >> 1));
+                col = col + 1 < a.A2 ? col : 0;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ek + row * rowstride + col),
+                                                 (__attribute__((address_space(3))) void *)(dst + m * 128), 16, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            cf_barrier();                              // B1: E_k is in LDS, phase A of slice k is done
-            cf_barrier();                              // B2: phase B of slice k is done, El may be overwritten
+        };
+        __syncthreads();                               // W staged (all waves)
+        if constexpr (EBUF == 2) {
+            // two images: E_{k+1} travels while the others are in phase B of slice k and phase A of k + 1
+            // (short phases -- small ranks -- would otherwise wait for the load at every B1)
+            if (k_beg < k_end) fill(k_beg);
+            for (int k = k_beg; k < k_end; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CF_STAMP(1);
+                CF_BARRIER();                          // B1: E_k is in LDS
+                CF_STAMP(2);
+                if (k + 1 < k_end) fill(k + 1);        // image (k + 1) & 1 was last read in phase B of slice k - 1
+                CF_STAMP(3);
+                CF_BARRIER();                          // B2
+                CF_STAMP(4);
+            }
+        } else {
+            for (int k = k_beg; k < k_end; ++k) {
+                CF_STAMP(0);
+                fill(k);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CF_STAMP(1);
+                CF_BARRIER();                          // B1: E_k is in LDS, phase A of slice k is done
+                CF_STAMP(2);
+                CF_STAMP(3);
+                CF_BARRIER();                          // B2: phase B of slice k is done, El may be overwritten
+                CF_STAMP(4);
+            }
         }
         return;
     }
@@ -141,17 +168,24 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     // ---- compute wave: rows j0 .. j0 + 15 of the output
     const int j0 = 16 * w;
     const bool jok = j0 + x16 < a.J;
-    const uint32_t xlane = jok ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
+    const uint32_t xlane = (jok && !(a.diag & 1)) ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
     const int nkb_lane = a.K1 > kq ? (a.K1 - kq + 3) >> 2 : 0;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(uniform_ptr(a.X[prob]), a.x_extent * 8);
-    const uint32_t xstep = (uint32_t)(4 * a.x_c * 8), kstep = (uint32_t)(a.x_k * 8);
-    const int ITER = (KB1 + D - 1) / D, KBP = ITER * D;
-    auto xload = [&](int k, int kb) -> double {
-        return ld8(rx, (kb < nkb_lane && k < k_end) ? xlane : OOB_OFF, (uint32_t)k * kstep + (uint32_t)kb * xstep);
+    // wave-uniform by construction; said so explicitly, or a value the register allocator parks in a
+    // vector register turns every load below into a waterfall loop
+    const uint32_t xstep = __builtin_amdgcn_readfirstlane((uint32_t)(4 * a.x_c * 8));
+    const uint32_t kstep = __builtin_amdgcn_readfirstlane((uint32_t)(a.x_k * 8));
+    static_assert(UNR % D == 0, "the unrolled body must keep the ring slots static");
+    // k-blocks are issued in straight-line runs of UNR (the compiler's wait counts are exact inside a run;
+    // at a loop edge it waits for every load in flight); a slice is padded to whole runs
+    const int ITER = (KB1 + UNR - 1) / UNR, KBP = ITER * UNR;
+    // fragment kb of slice k: per-lane row / k offset fixed, the (slice, k-block) part is a scalar offset
+    auto xload = [&](bool ok, uint32_t so, int kb) -> double {
+        return ld8(rx, (ok && kb < nkb_lane) ? xlane : OOB_OFF, __builtin_amdgcn_readfirstlane(so));
     };
     double ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = xload(k_beg, d);
+    for (int d = 0; d < D; ++d) ring[d] = xload(k_beg < k_end, (uint32_t)k_beg * kstep + (uint32_t)d * xstep, d);
 
     v4d acc2[NNF ? NNF : 1];
     double acc2s[STRN ? STRN : 1];
@@ -182,26 +216,54 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
 #pragma unroll
         for (int q = 0; q < STRQ; ++q) acc1s[q] = 0.0;
 
-        // ---- phase A
+        CF_STAMP(0);
+        // ---- phase A.  Each k-block: the W fragments of the NEXT k-block are requested from LDS before this
+        // one's matrix instructions are issued (a wave then covers its own LDS latency -- the matrix pipe
+        // serves the older wave of a SIMD first, so the younger one cannot be counted on to fill the gaps),
+        // and the ring slot is reloaded AFTER its fragment has been consumed, so that the load can land in the
+        // same register (reloading first forces a copy at the loop edge behind an s_waitcnt vmcnt(0)).
+        double af[NQF ? NQF : 1], sf[STRQ ? STRQ : 1];
+        auto wfetch = [&](int kb, double (&f)[NQF ? NQF : 1], double (&g)[STRQ ? STRQ : 1]) {
+            const double *wk = Wl + kb * 4 * AP;          // kb = KB1 reads the first rows of the E image: finite, unused
+#pragma unroll
+            for (int p = 0; p < NQF; ++p) f[p] = wk[wl_lane + 32 * p];
+#pragma unroll
+            for (int q = 0; q < STRQ; ++q) g[q] = wk[ws_lane + 8 * q];
+        };
+        wfetch(0, af, sf);
+        // kb = base + u with u < UNR static; `last`: this run ends the slice, its final D reloads are the next slice's
+        auto kblock = [&](int base, int u, bool live, bool last, uint32_t so_run, uint32_t so_next) {
+            const int kb = base + u, d = u % D;
+            double afn[NQF ? NQF : 1], sfn[STRQ ? STRQ : 1];
+            if (live) wfetch(kb + 1 < KB1 ? kb + 1 : KB1 - 1, afn, sfn);
+            const double bf = ring[d];
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < NQF; ++p) acc1[p] = mfma16(af[p], bf, acc1[p]);
+#pragma unroll
+                for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
+            }
+            if (u + D < UNR) ring[d] = xload(true, so_run + (uint32_t)(u + D) * xstep, kb + D);
+            else ring[d] = xload(!last || k + 1 < k_end, so_next + (uint32_t)(u + D - UNR) * xstep, last ? u + D - UNR : kb + D);
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < NQF; ++p) af[p] = afn[p];
+#pragma unroll
+                for (int q = 0; q < STRQ; ++q) sf[q] = sfn[q];
+            }
+        };
+        const int FULL = KB1 / UNR;
+        const uint32_t so_k = (uint32_t)k * kstep;
         for (int it = 0; it < ITER; ++it) {
+            const bool last = it == ITER - 1;
+            const uint32_t so_run = so_k + (uint32_t)(it * UNR) * xstep;
+            const uint32_t so_next = last ? so_k + kstep : so_run + (uint32_t)UNR * xstep;
+            if (it < FULL) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int kb = it * D + d;
-                const double bf = ring[d];
-                const int kbn = kb + D;
-                ring[d] = kbn < KBP ? xload(k, kbn) : xload(k + 1, kbn - KBP);
-                if (kb < KB1) {
-                    const double *wk = Wl + kb * 4 * AP;
-                    double af[NQF ? NQF : 1], sf[STRQ ? STRQ : 1];
+                for (int u = 0; u < UNR; ++u) kblock(it * UNR, u, true, last, so_run, so_next);
+            } else {
 #pragma unroll
-                    for (int p = 0; p < NQF; ++p) af[p] = wk[wl_lane + 32 * p];
-#pragma unroll
-                    for (int q = 0; q < STRQ; ++q) sf[q] = wk[ws_lane + 8 * q];
-#pragma unroll
-                    for (int p = 0; p < NQF; ++p) acc1[p] = mfma16(af[p], bf, acc1[p]);
-#pragma unroll
-                    for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
-                }
+                for (int u = 0; u < UNR; ++u) kblock(it * UNR, u, it * UNR + u < KB1, last, so_run, so_next);
             }
         }
         if constexpr (WT) {
@@ -217,7 +279,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
             for (int q = 0; q < STRQ; ++q)
                 st8(rt, (jok && 16 * NQF + 4 * q + kq < a.A) ? tl + (uint32_t)((16 * NQF + 4 * q) * nJ * 8) : OOB_OFF, acc1s[q]);
         }
-        cf_barrier();                                  // B1
+        CF_STAMP(1);
+        CF_BARRIER();                                  // B1
+        CF_STAMP(2);
 
         // ---- phase B: k-block kap = 4 p + t of T is register t of tile p
 #pragma unroll
@@ -226,7 +290,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
             for (int t = 0; t < (p < NQF ? 4 : STRQ); ++t) {
                 const int kap = 4 * p + t;
                 const double af = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
-                const double *ek = El + kap * 4 * A2P;
+                const double *ek = El + (EBUF == 2 ? (k & 1) * a.eunits * 2 : 0) + kap * 4 * A2P;
                 double bf[NNF ? NNF : 1], bs[STRN ? STRN : 1];
 #pragma unroll
                 for (int nn = 0; nn < NNF; ++nn) bf[nn] = ek[el_lane + 32 * nn];
@@ -241,7 +305,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
                 for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af, bs[q], acc2s[q]);
             }
         }
-        cf_barrier();                                  // B2
+        CF_STAMP(3);
+        CF_BARRIER();                                  // B2
+        CF_STAMP(4);
     }
 
     // ---- partial result of this workgroup: slab[problem][g][j][a']
@@ -272,6 +338,6 @@ struct ChainStepArgs {
     double *const *T;            // nullptr, or nb buffers (A, n, J) contiguous
     double *const *Out;          // nb results (J x A2) contiguous
 };
-int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st);
+int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool force = false);
 
 }  // namespace ttsk

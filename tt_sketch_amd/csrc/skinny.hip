@@ -15,7 +15,6 @@ int launch_skinny_r_1(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t 
 int launch_skinny_r_2(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
 int launch_skinny_r_3(const SkinnyR &a, int nmt, int nnt, int grid, hipStream_t st);
 
-struct ReduceOut { double *C[SK_MAXB]; };
 // out[m, n] (+)= alpha sum_c slab[c][m][n] per (problem, row tile) y; 16 chunk lanes x 16 consecutive n
 __global__ __launch_bounds__(256) void skinny_r_reduce(const double *__restrict__ slab_all, int chunks, int M, int N,
                                                        int m_tiles, int64_t Mtot, ReduceOut outs, int64_t c_m,

@@ -4,6 +4,7 @@
 #include <vector>
 #include "common.h"
 #include "skinny.h"
+#include "chain_fused.h"
 
 namespace ttsk {
 
@@ -33,6 +34,9 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
                  tiles / 100 % 10, tiles % 10, bk ? 4 : 5, tiles / 1000);
     else if (family == 5)
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "small_gemm_kernel");
+    else if (family == 6)   // fused chain step: tiles = 100 * full tiles + 10 * strips + (T written)
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "chain_step_kernel<%d, %d, %d, %d, 5, %s, 1>", tiles / 100, tiles / 10 % 10,
+                 tiles / 100, tiles / 10 % 10, tiles % 10 ? "true" : "false");
     else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_r_kernel<%d, %d, 4>", tiles / 10, tiles % 10);
     else
@@ -250,7 +254,20 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             CK(gemm_batch(5, nb, desc2(sn, rhop, 1, nn, nn * sp, 0, sp, 0, rhop, 1, rhop, 1, 0), p, stream, st));
             continue;
         }
-        // preferred: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (a product batched over k whose batch index
+        // first choice: both products in one launch, T never written (chain_fused.h)
+        {
+            const double *Wp[SK_MAXB], *Xp[SK_MAXB];
+            double *Op[SK_MAXB];
+            for (int b = 0; b < nb; ++b) { Wp[b] = ws(b) + offR[j - 1]; Xp[b] = Xc(b, mu); Op[b] = ws(b) + offR[j]; }
+            ChainStepArgs cs{nb, (int)nn, (int)sp, (int)rho, (int)rhop, (int)sn, Wp, rho, Xp, nn * sp, sp, 1, sn * nn * sp,
+                             DR[j], nullptr, Op};
+            g_cls = 1;
+            const int fz = (sp <= 128 && sn <= 128 && rho <= 128 && rhop <= 128) ? chain_fused_try(cs, stream, st) : 0;
+            g_cls = NCLS - 1;
+            if (fz < 0) return fz;
+            if (fz == 1) continue;
+        }
+        // otherwise: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (a product batched over k whose batch index
         // joins the streamed index), so that both operands of GEMM2 are contiguous along their output index
         for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offR[j - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offTR; }
         ttsk_gemm_desc g1{};
@@ -284,6 +301,21 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             continue;
         }
         const int64_t lfull = lt[mu];
+        if (mu < d - 1) {
+            // first choice: T and L_mu from one launch (chain_fused.h); T is still stored, Psi_mu needs it
+            const double *Wp[SK_MAXB], *Xp[SK_MAXB];
+            double *Op[SK_MAXB], *Tp[SK_MAXB];
+            for (int b = 0; b < nb; ++b) {
+                Wp[b] = ws(b) + offL[mu - 1]; Xp[b] = Xc(b, mu); Op[b] = ws(b) + offL[mu]; Tp[b] = ws(b) + offT[mu];
+            }
+            ChainStepArgs cs{nb, (int)nn, (int)sn, (int)lfull, (int)lt[mu + 1], (int)sp, Wp, lfull, Xp, 1, sp, nn * sp,
+                             sn * nn * sp, DL[mu], Tp, Op};
+            g_cls = 3;
+            const int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
+            g_cls = NCLS - 1;
+            if (fz < 0) return fz;
+            if (fz == 1) continue;
+        }
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
         for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offL[mu - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offT[mu]; }
         CK(gemm_batch(mu == d - 1 ? 5 : 2, nb, desc2(lfull, nn * sp, 1, sn, 1, 0, lfull, 0, nn * sp, 1, nn * sp, 1, 0), p,
