@@ -168,8 +168,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     // ---- compute wave: rows j0 .. j0 + 15 of the output
     const int j0 = 16 * w;
     const bool jok = j0 + x16 < a.J;
-    const uint32_t xlane = (jok && !(a.diag & 1)) ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
-    const int nkb_lane = a.K1 > kq ? (a.K1 - kq + 3) >> 2 : 0;
+    const uint32_t xlane = !(a.diag & 1) ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(uniform_ptr(a.X[prob]), a.x_extent * 8);
     // wave-uniform by construction; said so explicitly, or a value the register allocator parks in a
     // vector register turns every load below into a waterfall loop
@@ -178,14 +177,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     static_assert(UNR % D == 0, "the unrolled body must keep the ring slots static");
     // k-blocks are issued in straight-line runs of UNR (the compiler's wait counts are exact inside a run;
     // at a loop edge it waits for every load in flight); a slice is padded to whole runs
-    const int ITER = (KB1 + UNR - 1) / UNR, KBP = ITER * UNR;
-    // fragment kb of slice k: per-lane row / k offset fixed, the (slice, k-block) part is a scalar offset
-    auto xload = [&](bool ok, uint32_t so, int kb) -> double {
-        return ld8(rx, (ok && kb < nkb_lane) ? xlane : OOB_OFF, __builtin_amdgcn_readfirstlane(so));
-    };
+    const int ITER = (KB1 + UNR - 1) / UNR, KBD = (KB1 + D - 1) / D * D;
+    // fragment kb of slice k: per-lane (row, k) offset fixed, the (slice, k-block) part a scalar offset.  No
+    // masks: k beyond K1 meets the zero rows of the W image, rows beyond J give output rows that are never
+    // stored, a prefetch past the workgroup's last slice is unused, and whatever lies beyond the core reads
+    // as 0 through the descriptor's range check.
+    auto xload = [&](uint32_t so) -> double { return ld8(rx, xlane, __builtin_amdgcn_readfirstlane(so)); };
     double ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = xload(k_beg < k_end, (uint32_t)k_beg * kstep + (uint32_t)d * xstep, d);
+    for (int d = 0; d < D; ++d) ring[d] = xload((uint32_t)k_beg * kstep + (uint32_t)d * xstep);
 
     v4d acc2[NNF ? NNF : 1];
     double acc2s[STRN ? STRN : 1];
@@ -223,19 +223,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         // and the ring slot is reloaded AFTER its fragment has been consumed, so that the load can land in the
         // same register (reloading first forces a copy at the loop edge behind an s_waitcnt vmcnt(0)).
         double af[NQF ? NQF : 1], sf[STRQ ? STRQ : 1];
-        auto wfetch = [&](int kb, double (&f)[NQF ? NQF : 1], double (&g)[STRQ ? STRQ : 1]) {
-            const double *wk = Wl + kb * 4 * AP;          // kb = KB1 reads the first rows of the E image: finite, unused
+        // fragments of k-block (run base) + u: compile-time offsets from the run's base address (u = UNR, the
+        // look-ahead of a run's last k-block, reads the rows behind the W image: finite, unused)
+        auto wfetch = [&](const double *wrun, int u, double (&f)[NQF ? NQF : 1], double (&g)[STRQ ? STRQ : 1]) {
 #pragma unroll
-            for (int p = 0; p < NQF; ++p) f[p] = wk[wl_lane + 32 * p];
+            for (int p = 0; p < NQF; ++p) f[p] = wrun[wl_lane + u * 4 * AP + 32 * p];
 #pragma unroll
-            for (int q = 0; q < STRQ; ++q) g[q] = wk[ws_lane + 8 * q];
+            for (int q = 0; q < STRQ; ++q) g[q] = wrun[ws_lane + u * 4 * AP + 8 * q];
         };
-        wfetch(0, af, sf);
-        // kb = base + u with u < UNR static; `last`: this run ends the slice, its final D reloads are the next slice's
-        auto kblock = [&](int base, int u, bool live, bool last, uint32_t so_run, uint32_t so_next) {
-            const int kb = base + u, d = u % D;
+        wfetch(Wl, 0, af, sf);
+        uint32_t so = (uint32_t)k * kstep + (uint32_t)D * xstep;      // scalar offset of the next fragment to request
+        // kb = base + u with u < UNR static; the D reloads of the slice's last D k-blocks (padded to a multiple of
+        // D: KBD) are the first fragments of the next slice
+        auto kblock = [&](const double *wrun, int u, bool live, bool wrap) {
+            const int d = u % D;
             double afn[NQF ? NQF : 1], sfn[STRQ ? STRQ : 1];
-            if (live) wfetch(kb + 1 < KB1 ? kb + 1 : KB1 - 1, afn, sfn);
+            if (live) wfetch(wrun, u + 1, afn, sfn);
             const double bf = ring[d];
             if (live) {
 #pragma unroll
@@ -243,8 +246,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
 #pragma unroll
                 for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
             }
-            if (u + D < UNR) ring[d] = xload(true, so_run + (uint32_t)(u + D) * xstep, kb + D);
-            else ring[d] = xload(!last || k + 1 < k_end, so_next + (uint32_t)(u + D - UNR) * xstep, last ? u + D - UNR : kb + D);
+            if (wrap) so = (uint32_t)(k + 1) * kstep;
+            ring[d] = xload(so);
+            so += xstep;
             if (live) {
 #pragma unroll
                 for (int p = 0; p < NQF; ++p) af[p] = afn[p];
@@ -253,17 +257,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
             }
         };
         const int FULL = KB1 / UNR;
-        const uint32_t so_k = (uint32_t)k * kstep;
         for (int it = 0; it < ITER; ++it) {
-            const bool last = it == ITER - 1;
-            const uint32_t so_run = so_k + (uint32_t)(it * UNR) * xstep;
-            const uint32_t so_next = last ? so_k + kstep : so_run + (uint32_t)UNR * xstep;
+            const double *wrun = Wl + it * UNR * 4 * AP;
             if (it < FULL) {
+                const bool last = (it + 1) * UNR == KBD;          // (then KB1 is a multiple of UNR)
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) kblock(it * UNR, u, true, last, so_run, so_next);
+                for (int u = 0; u < UNR; ++u) kblock(wrun, u, true, last && u + D == UNR);
             } else {
+                // the run that ends the slice inside: k-blocks up to KB1 are live, up to KBD they only keep the ring turning
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) kblock(it * UNR, u, it * UNR + u < KB1, last, so_run, so_next);
+                for (int u = 0; u < UNR; ++u) {
+                    const int kb = it * UNR + u;
+                    if (kb < KBD) kblock(wrun, u, kb < KB1, kb + D == KBD);
+                }
             }
         }
         if constexpr (WT) {
@@ -283,26 +289,44 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         CF_BARRIER();                                  // B1
         CF_STAMP(2);
 
-        // ---- phase B: k-block kap = 4 p + t of T is register t of tile p
+        // ---- phase B: k-block kap = 4 p + t of T is register t of tile p.  Same look-ahead: the E fragments of
+        // k-block kap + 1 are requested before the matrix instructions of kap (left to itself the compiler
+        // requests them right in front of their first use and every k-block waits out the LDS latency).
+        {
+            const double *eb = El + (EBUF == 2 ? (k & 1) * a.eunits * 2 : 0);
+            double bf[NNF ? NNF : 1], bs[STRN ? STRN : 1];
+            // per-slice copies of the lane offsets the compiler cannot see through: it then forms each k-block's
+            // address with one add where it is used, instead of keeping 2 x 25 precomputed addresses alive across
+            // the slice loop (and spilling them into the phase)
+            int el0 = el_lane, es0 = es_lane + 4 * (es_col >> 1) + (es_col & 1);
+            asm volatile("" : "+v"(el0), "+v"(es0));
+            auto efetch = [&](int kap, double (&f)[NNF ? NNF : 1], double (&g)[STRN ? STRN : 1]) {
 #pragma unroll
-        for (int p = 0; p < NQF + (STRQ ? 1 : 0); ++p) {
+                for (int nn = 0; nn < NNF; ++nn) f[nn] = eb[el0 + kap * 4 * A2P + 32 * nn];
 #pragma unroll
-            for (int t = 0; t < (p < NQF ? 4 : STRQ); ++t) {
-                const int kap = 4 * p + t;
-                const double af = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
-                const double *ek = El + (EBUF == 2 ? (k & 1) * a.eunits * 2 : 0) + kap * 4 * A2P;
-                double bf[NNF ? NNF : 1], bs[STRN ? STRN : 1];
+                for (int q = 0; q < STRN; ++q) g[q] = eb[es0 + kap * 4 * A2P + 8 * q];
+            };
+            efetch(0, bf, bs);
+            constexpr int KB2C = 4 * NQF + STRQ;
 #pragma unroll
-                for (int nn = 0; nn < NNF; ++nn) bf[nn] = ek[el_lane + 32 * nn];
+            for (int p = 0; p < NQF + (STRQ ? 1 : 0); ++p) {
 #pragma unroll
-                for (int q = 0; q < STRN; ++q) {
-                    const int col = es_col + 4 * q;
-                    bs[q] = ek[es_lane + 4 * (col >> 1) + (col & 1)];
+                for (int t = 0; t < (p < NQF ? 4 : STRQ); ++t) {
+                    const int kap = 4 * p + t;
+                    const double af2 = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
+                    double bfn[NNF ? NNF : 1], bsn[STRN ? STRN : 1];
+                    if (kap + 1 < KB2C) efetch(kap + 1, bfn, bsn);
+#pragma unroll
+                    for (int nn = 0; nn < NNF; ++nn) acc2[nn] = mfma16(af2, bf[nn], acc2[nn]);
+#pragma unroll
+                    for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af2, bs[q], acc2s[q]);
+                    if (kap + 1 < KB2C) {
+#pragma unroll
+                        for (int nn = 0; nn < NNF; ++nn) bf[nn] = bfn[nn];
+#pragma unroll
+                        for (int q = 0; q < STRN; ++q) bs[q] = bsn[q];
+                    }
                 }
-#pragma unroll
-                for (int nn = 0; nn < NNF; ++nn) acc2[nn] = mfma16(af, bf[nn], acc2[nn]);
-#pragma unroll
-                for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af, bs[q], acc2s[q]);
             }
         }
         CF_STAMP(3);

@@ -4,7 +4,20 @@
 
 namespace ttsk {
 
-int launch_chain_step(const ChainStep &a, int nf, int str, bool wt, int ebuf, int depth, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_a(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_b(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_c(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_d(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_e(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+
+static int launch_chain_step(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st)
+{
+    if (nf <= 2) return launch_chain_step_a(a, nf, str, wt, ebuf, lds, grid, st);
+    if (nf <= 4) return launch_chain_step_b(a, nf, str, wt, ebuf, lds, grid, st);
+    if (nf == 5) return launch_chain_step_c(a, nf, str, wt, ebuf, lds, grid, st);
+    if (nf == 6) return launch_chain_step_d(a, nf, str, wt, ebuf, lds, grid, st);
+    return launch_chain_step_e(a, nf, str, wt, ebuf, lds, grid, st);
+}
 
 static int cf_num_cu()
 {
@@ -59,13 +72,11 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
     const int64_t units = (int64_t)2 * KB2 * a.A2P;                      // 16-byte units of the E image
     a.eunits = (int)cdiv(units, 64) * 64;
     if (a.eunits / 64 > CF_MAX_DMA) return 0;
-    // a second E image when it fits: the load of E_{k+1} then has a whole slice to land
-    static int ebuf_force = [] { const char *e = getenv("TTSK_CF_EBUF"); return e ? atoi(e) : 0; }();
-    int ebuf = ((size_t)a.ebase + (size_t)a.eunits * 4) * 8 <= 160 * 1024 ? 2 : 1;
-    if (ebuf_force == 1) ebuf = 1;
+    // two E images for the small structures (the load of E_{k+1} then has a whole slice to land: their
+    // phases are too short to hide it), one for the large ones (no LDS room; their phases are long)
+    const int ebuf = nq <= 4 ? 2 : 1;
     const size_t lds = ((size_t)a.ebase + (size_t)a.eunits * 2 * ebuf) * 8;
     if (lds > 160 * 1024) return 0;
-    static int depth = [] { const char *e = getenv("TTSK_CF_D"); return e ? atoi(e) : 5; }();
     { static int dg = [] { const char *e = getenv("TTSK_CF_DIAG"); return e ? atoi(e) : 0; }(); a.diag = dg; }
     // 32-bit byte offsets: the X walk (incl. the masked prefetch one slice past the end) and T
     if ((c.x_extent + c.x_k + 132 * c.x_c) * 8 >= (1ll << 32) - 64) return 0;
@@ -100,7 +111,7 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
         (void)hipMemset(stamps_dev, 0, 8 * 8 * 8 * 8);
         a.stamps = stamps_dev;
     }
-    int rc = launch_chain_step(a, nq, sq, wt, ebuf, depth, lds, (int)nslab, st);
+    int rc = launch_chain_step(a, nq, sq, wt, ebuf, lds, (int)nslab, st);
     if (stamps_on) {
         long long h[8 * 8 * 8];
         (void)hipStreamSynchronize(st);

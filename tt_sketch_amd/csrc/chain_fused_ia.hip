@@ -1,0 +1,18 @@
+// Explicit instantiations of chain_step_kernel: ranks of 1/2 full 16-wide tiles (+ 0..2 strips of 4), with and
+// without the T side output; one translation unit per tile count keeps the parallel build short.
+#include "chain_fused_inst.h"
+
+namespace ttsk {
+
+int launch_chain_step_a(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st)
+{
+    TTSK_CF_CASE(1, 0, 2)
+    TTSK_CF_CASE(1, 1, 2)
+    TTSK_CF_CASE(1, 2, 2)
+    TTSK_CF_CASE(2, 0, 2)
+    TTSK_CF_CASE(2, 1, 2)
+    TTSK_CF_CASE(2, 2, 2)
+    return 1;
+}
+
+}  // namespace ttsk
