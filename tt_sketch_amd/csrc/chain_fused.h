@@ -306,26 +306,29 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
 #pragma unroll
                 for (int q = 0; q < STRN; ++q) g[q] = eb[es0 + kap * 4 * A2P + 8 * q];
             };
+            // two fragment sets used in turn (even / odd k-blocks): with one set and a copy the compiler merges the
+            // look-ahead registers with the current ones and the requests slide back behind the matrix instructions
+            double bf2[NNF ? NNF : 1], bs2[STRN ? STRN : 1];
             efetch(0, bf, bs);
             constexpr int KB2C = 4 * NQF + STRQ;
 #pragma unroll
-            for (int p = 0; p < NQF + (STRQ ? 1 : 0); ++p) {
+            for (int kap = 0; kap < KB2C; ++kap) {
+                const int p = kap >> 2, t = kap & 3;
+                const double af2 = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
+                if (kap & 1) {
+                    if (kap + 1 < KB2C) efetch(kap + 1, bf, bs);
+                    __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of this k-block's matrix instructions
 #pragma unroll
-                for (int t = 0; t < (p < NQF ? 4 : STRQ); ++t) {
-                    const int kap = 4 * p + t;
-                    const double af2 = p < NQF ? acc1[p < NQF ? p : 0][t] : acc1s[t < STRQ ? t : 0];
-                    double bfn[NNF ? NNF : 1], bsn[STRN ? STRN : 1];
-                    if (kap + 1 < KB2C) efetch(kap + 1, bfn, bsn);
+                    for (int nn = 0; nn < NNF; ++nn) acc2[nn] = mfma16(af2, bf2[nn], acc2[nn]);
+#pragma unroll
+                    for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af2, bs2[q], acc2s[q]);
+                } else {
+                    if (kap + 1 < KB2C) efetch(kap + 1, bf2, bs2);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nn = 0; nn < NNF; ++nn) acc2[nn] = mfma16(af2, bf[nn], acc2[nn]);
 #pragma unroll
                     for (int q = 0; q < STRN; ++q) acc2s[q] = mfma4(af2, bs[q], acc2s[q]);
-                    if (kap + 1 < KB2C) {
-#pragma unroll
-                        for (int nn = 0; nn < NNF; ++nn) bf[nn] = bfn[nn];
-#pragma unroll
-                        for (int q = 0; q < STRN; ++q) bs[q] = bsn[q];
-                    }
                 }
             }
         }
