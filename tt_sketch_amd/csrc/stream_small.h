@@ -1,0 +1,170 @@
+// Psi_mu = T_mu R_mu (tensor_train_sketch.py:28-34) as a streamed x small product in the style of
+// chain_fused.h:
+//   C[j][a] (+)= sum_c S[j][c] W[c][a]       j ~ 10^4 rows streamed once, K1, A <= 128
+// W sits in LDS in the pair-interleaved image of chain_fused.h (conflict-free fragment reads), every one of
+// the 8 waves of a workgroup walks its own 16-row tiles of S: fragments straight from memory through a
+// register ring, the W fragments of the next k-block requested before this one's matrix instructions,
+// 25 k-blocks per straight-line run, partial tiles of A as 4-wide strips (v_mfma_f64_4x4x4).  With
+// mfma(A = S fragment, B = W fragment) a result register holds 16 consecutive a of one row: 128-byte stores.
+// No barrier after W is staged.  The older skinny_s_kernel (skinny.h) covers the same product for every
+// stride pattern; this one takes the contiguous case the TT sketch produces.
+#pragma once
+#include "skinny.h"
+
+namespace ttsk {
+
+struct StreamSmall {
+    const double *S[SK_MAXB];
+    const double *W[SK_MAXB];
+    double *C[SK_MAXB];
+    int nb, wpp;                 // problems, workgroups per problem
+    int J, K1, A;
+    int64_t s_j, w_c, c_j;       // row strides (elements): S rows, W rows, C rows; columns contiguous
+    int64_t s_extent, c_extent;
+    int AP;
+    int accumulate;
+};
+
+template <int NF, int STR, int D, int UNR = 5 * D>
+__global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
+{
+    static_assert(UNR % D == 0, "the unrolled body must keep the ring slots static");
+    extern __shared__ double ss_lds[];
+    double *Wl = ss_lds;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int x16 = lane & 15, kq = lane >> 4;
+    const int prob = blockIdx.x / a.wpp, g = blockIdx.x - prob * a.wpp;
+    const int KB1 = (a.K1 + 3) >> 2, AP = a.AP;
+    {
+        const double *Wp = uniform_ptr(a.W[prob]);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, ((int64_t)(a.K1 - 1) * a.w_c + a.A) * 8);
+        const int total = 4 * (KB1 + 1) * AP;          // one k-block of zeros behind the image: the last look-ahead
+        constexpr int BATCH = 10;
+        for (int e0 = tid; e0 < total; e0 += 512 * BATCH) {
+            double v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int c = e / AP, col = e - c * AP;
+                v[u] = ld8(rw, (e < total && c < a.K1 && col < a.A) ? (uint32_t)(((int64_t)c * a.w_c + col) * 8) : OOB_OFF, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int e = e0 + 512 * u;
+                const int c = e / AP, col = e - c * AP;
+                if (e < total) Wl[(c >> 1) * 2 * AP + 2 * col + (c & 1)] = v[u];
+            }
+        }
+    }
+    const int ntiles = (a.J + 15) >> 4;
+    const int tstep = a.wpp * 8;                       // tiles between two visits of this wave
+    int tile = g * 8 + w;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(uniform_ptr(a.S[prob]), a.s_extent * 8);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(uniform_ptr(a.C[prob]), a.c_extent * 8);
+    // this lane's (row, k) offset inside a tile; the (tile, k-block) part is a scalar offset.  No masks: k
+    // beyond K1 meets zero rows of the W image, rows beyond J are never stored, past the end reads 0.
+    const uint32_t slane = (uint32_t)(((int64_t)x16 * a.s_j + kq) * 8);
+    const uint32_t tstride = __builtin_amdgcn_readfirstlane((uint32_t)(16 * a.s_j * 8));
+    auto sload = [&](uint32_t so) -> double { return ld8(rs, slane, __builtin_amdgcn_readfirstlane(so)); };
+    const int ITER = (KB1 + UNR - 1) / UNR, KBD = (KB1 + D - 1) / D * D;
+    double ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = sload((uint32_t)tile * tstride + (uint32_t)d * 32u);
+    const int wl_lane = (kq >> 1) * 2 * AP + 2 * x16 + (kq & 1);
+    const int ws_lane = (kq >> 1) * 2 * AP + 2 * (16 * NF + (x16 & 3)) + (kq & 1);
+    __syncthreads();                                   // W staged; from here on the waves run free
+
+    for (; tile < ntiles; tile += tstep) {
+        v4d acc[NF ? NF : 1];
+        double accs[STR ? STR : 1];
+#pragma unroll
+        for (int p = 0; p < NF; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[p][t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < STR; ++q) accs[q] = 0.0;
+        double bf[NF ? NF : 1], sf[STR ? STR : 1];
+        auto wfetch = [&](const double *wrun, int u, double (&f)[NF ? NF : 1], double (&gq)[STR ? STR : 1]) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) f[p] = wrun[wl_lane + u * 4 * AP + 32 * p];
+#pragma unroll
+            for (int q = 0; q < STR; ++q) gq[q] = wrun[ws_lane + u * 4 * AP + 8 * q];
+        };
+        wfetch(Wl, 0, bf, sf);
+        uint32_t so = (uint32_t)tile * tstride + (uint32_t)D * 32u;
+        auto kblock = [&](const double *wrun, int u, bool live, bool wrap) {
+            const int d = u % D;
+            double bfn[NF ? NF : 1], sfn[STR ? STR : 1];
+            if (live) wfetch(wrun, u + 1, bfn, sfn);
+            const double af = ring[d];
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < NF; ++p) acc[p] = mfma16(af, bf[p], acc[p]);
+#pragma unroll
+                for (int q = 0; q < STR; ++q) accs[q] = mfma4(af, sf[q], accs[q]);
+            }
+            if (wrap) so = (uint32_t)(tile + tstep) * tstride;       // the first fragments of this wave's next tile
+            ring[d] = sload(so);
+            so += 32u;
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < NF; ++p) bf[p] = bfn[p];
+#pragma unroll
+                for (int q = 0; q < STR; ++q) sf[q] = sfn[q];
+            }
+        };
+        const int FULL = KB1 / UNR;
+        for (int it = 0; it < ITER; ++it) {
+            const double *wrun = Wl + it * UNR * 4 * AP;
+            if (it < FULL) {
+                const bool last = (it + 1) * UNR == KBD;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) kblock(wrun, u, true, last && u + D == UNR);
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int kb = it * UNR + u;
+                    if (kb < KBD) kblock(wrun, u, kb < KB1, kb + D == KBD);
+                }
+            }
+        }
+        // register t of tile p: row 16 tile + 4 t + kq, columns 16 p .. 16 p + 15
+        const int j0 = 16 * tile;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + 4 * t + kq;
+            const uint32_t ro = (uint32_t)(((int64_t)j * a.c_j + x16) * 8);
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                const uint32_t off = (j < a.J && 16 * p + x16 < a.A) ? ro + 128u * p : OOB_OFF;
+                double v = acc[p][t];
+                if (a.accumulate) v += ld8(rc, off, 0);
+                st8(rc, off, v);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < STR; ++q) {
+            // 4x4x4 result: lane (i = l >> 4, beta = (l >> 2) & 3, c = l & 3) holds row 4 beta + i, column c of the strip
+            const int j = j0 + 4 * ((lane >> 2) & 3) + kq, col = 16 * NF + 4 * q + (lane & 3);
+            const uint32_t off = (j < a.J && col < a.A) ? (uint32_t)(((int64_t)j * a.c_j + col) * 8) : OOB_OFF;
+            double v = accs[q];
+            if (a.accumulate) v += ld8(rc, off, 0);
+            st8(rc, off, v);
+        }
+    }
+}
+
+// 1 = launched, 0 = shape not covered, < 0 = error
+struct StreamSmallArgs {
+    int nb, J, K1, A;
+    const double *const *S;      // nb operands (J x K1), row stride s_j, columns contiguous
+    int64_t s_j;
+    const double *const *W;      // nb small operands (K1 x A), row stride w_c
+    int64_t w_c;
+    double *const *C;            // nb results (J x A), row stride c_j
+    int64_t c_j;
+    int accumulate;
+};
+int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st);
+
+}  // namespace ttsk

@@ -1,0 +1,85 @@
+// Host side of stream_small_kernel (stream_small.h) + its instantiations.
+#include <cstdlib>
+#include "stream_small.h"
+
+namespace ttsk {
+
+template <int NF, int STR>
+static int launch_ss_one(const StreamSmall &a, size_t lds, int grid, hipStream_t st)
+{
+    auto kern = stream_small_kernel<NF, STR, 5, 25>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+static int launch_ss(const StreamSmall &a, int nf, int str, size_t lds, int grid, hipStream_t st)
+{
+#define TTSK_SS_CASE(NF, STR) if (nf == NF && str == STR) return launch_ss_one<NF, STR>(a, lds, grid, st);
+    TTSK_SS_CASE(1, 0) TTSK_SS_CASE(1, 1) TTSK_SS_CASE(1, 2) TTSK_SS_CASE(2, 0) TTSK_SS_CASE(2, 1) TTSK_SS_CASE(2, 2)
+    TTSK_SS_CASE(3, 0) TTSK_SS_CASE(3, 1) TTSK_SS_CASE(3, 2) TTSK_SS_CASE(4, 0) TTSK_SS_CASE(4, 1) TTSK_SS_CASE(4, 2)
+    TTSK_SS_CASE(5, 0) TTSK_SS_CASE(5, 1) TTSK_SS_CASE(5, 2) TTSK_SS_CASE(6, 0) TTSK_SS_CASE(6, 1) TTSK_SS_CASE(6, 2)
+    TTSK_SS_CASE(7, 0)
+#undef TTSK_SS_CASE
+    return 1;
+}
+
+static int ss_num_cu()
+{
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
+int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st)
+{
+    (void)stream;
+    static int on = [] { const char *e = getenv("TTSK_STREAM_SMALL"); return e ? atoi(e) : 1; }();
+    if (!on || c.nb < 1 || c.nb > SK_MAXB) return 0;
+    if (c.K1 < 1 || c.K1 > 128 || c.A < 4 || c.A > 112 || c.J < 1024) return 0;
+    if (c.s_j < c.K1 || c.w_c < c.A || c.c_j < c.A) return 0;
+    int nf = c.A / 16, str;
+    const int rem = c.A % 16;
+    if (rem == 0) str = 0;
+    else if (rem <= 4) str = 1;
+    else if (rem <= 8) str = 2;
+    else { nf += 1; str = 0; }
+    if (nf < 1 || nf + (str ? 1 : 0) > 7) return 0;
+    StreamSmall a{};
+    a.nb = c.nb; a.J = c.J; a.K1 = c.K1; a.A = c.A;
+    a.s_j = c.s_j; a.w_c = c.w_c; a.c_j = c.c_j;
+    a.accumulate = c.accumulate;
+    a.AP = 16 * nf + 4 * str;
+    const int KB1 = (c.K1 + 3) / 4;
+    const size_t lds = (size_t)4 * (KB1 + 1) * a.AP * 8;
+    if (lds > 160 * 1024) return 0;
+    const int ntiles = (c.J + 15) / 16;
+    int wpp = ss_num_cu() / c.nb > 0 ? ss_num_cu() / c.nb : 1;
+    if (wpp > (ntiles + 7) / 8) wpp = (ntiles + 7) / 8;
+    a.wpp = wpp;
+    a.s_extent = (int64_t)(c.J - 1) * c.s_j + c.K1;
+    a.c_extent = (int64_t)(c.J - 1) * c.c_j + c.A;
+    // 32-bit byte offsets incl. the look-ahead one visit past the last tile
+    if (((int64_t)(ntiles + wpp * 8 + 2) * 16 * c.s_j + 256) * 8 >= (1ll << 32) - 64) return 0;
+    if (((int64_t)(ntiles + 1) * 16 * c.c_j + 256) * 8 >= (1ll << 32) - 64) return 0;
+    for (int b = 0; b < c.nb; ++b) {
+        if (((uintptr_t)c.S[b] | (uintptr_t)c.W[b] | (uintptr_t)c.C[b]) & 7) return 0;
+        a.S[b] = c.S[b]; a.W[b] = c.W[b]; a.C[b] = c.C[b];
+    }
+    const bool prof = prof_on();
+    if (prof) prof_open(st, 2.0 * c.nb * (double)c.J * c.K1 * c.A, 7, nf * 10 + str, false, false);
+    const int rc = launch_ss(a, nf, str, lds, c.nb * wpp, st);
+    if (prof) prof_close(st);
+    return rc == TTSK_OK ? 1 : (rc == 1 ? 0 : rc);
+}
+
+}  // namespace ttsk

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "skinny.h"
 #include "chain_fused.h"
+#include "stream_small.h"
 
 namespace ttsk {
 
@@ -34,6 +35,8 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
                  tiles / 100 % 10, tiles % 10, bk ? 4 : 5, tiles / 1000);
     else if (family == 5)
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "small_gemm_kernel");
+    else if (family == 7)   // streamed x small, contiguous form: tiles = 10 * full tiles + strips
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "stream_small_kernel<%d, %d, 5, 25>", tiles / 10, tiles % 10);
     else if (family == 6)   // fused chain step: tiles = 100 * full tiles + 10 * strips + (T written)
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "chain_step_kernel<%d, %d, %d, %d, 5, %s, 1>", tiles / 100, tiles / 10 % 10,
                  tiles / 100, tiles / 10 % 10, tiles % 10 ? "true" : "false");
@@ -366,7 +369,16 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             if (mu < d - 1) {
                 // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
                 for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offTs; p.B[b] = ws(b) + offRm; p.C[b] = outb(b) + psi_at[mu]; }
+                {
+                    StreamSmallArgs ss{nb, (int)(l * nn), (int)sp, (int)r, p.A, sp, p.B, ldr, p.C, r, accumulate};
+                    g_cls = 4;
+                    const int fz = (l * nn < (1ll << 30)) ? stream_small_try(ss, q, stq) : 0;
+                    g_cls = NCLS - 1;
+                    if (fz < 0) return fz;
+                    if (fz == 1) goto psi_done;
+                }
                 CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
+            psi_done:;
             } else {
                 // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
                 for (int b = 0; b < nb; ++b) {
