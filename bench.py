@@ -1,19 +1,30 @@
-"""Benchmark: TT-cores sketched / second (fp64) of stream_sketch on the north-star workload.
+"""Benchmark: TT-cores sketched / second (fp64) of the streaming TT sketch on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3|c2|c4|c5] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): TensorTrain d=6, n=200, TT-rank 100,
-TensorTrainDRM left rank 50 (r_out), right rank 100, all fp64, synthetic Gaussian cores.  A step
-sketches one such TT per GPU with inputs and DRMs resident in HBM (ttsk_tt_sketch: both chains,
-Omega, Psi).  With N > 1 ranks every rank sketches its own summand and ONE RCCL all-reduce sums
-the packed partial sketches (the sketch of the N-term TensorSum) -- weak scaling, value = cores
-sketched by all ranks per second.
+Default workload (BASELINE.json configs[2] / SURVEY.md 8d "C3", the configuration the metric is quoted on):
+TensorTrain d=6, n=200, TT-rank 100, TensorTrainDRM left rank 50 (r_out) / right rank 100, all fp64, synthetic
+Gaussian cores generated on the device.  A step sketches `--batch` such TTs per GPU in one batched pass
+(ttsk_tt_sketch_batch: both chains, Omega, Psi) with inputs and DRMs resident in HBM.
+
+  --scaling weak    (default) every rank sketches its own batch per step; with N > 1 the rank's partial
+                    sketches are summed and ONE RCCL all-reduce per step gives every rank the sketch of the
+                    whole N x batch term sum.  value = cores sketched by all ranks per second.
+  --scaling strong  a fixed job of `--items` TTs (default 128) is dealt over the ranks (shard_bounds); a step
+                    sketches the whole job: items / N per rank in batched passes, local sum, ONE all-reduce.
+                    At N = 1 this is the weak workload repeated items / batch times per step.
+  --config c2|c4|c5 the other BASELINE configurations on one GPU (c5 also shards its 32 terms over N ranks),
+                    with the roofline SURVEY.md 8d names for each.
+
+Ranks are launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; the launcher
+only sets RANK / LOCAL_RANK / WORLD_SIZE.  This process never imports torch: the RCCL id travels through
+tt_sketch_amd.rendezvous (files), barriers and the max-over-ranks clock are RCCL calls.
 
 The JSON line also carries
-  roofline      the dominant GEMM class of the pipeline: algorithmic flops / hipEvent time per
-                launch against the fp64 MFMA peak (78.6 TF/s data sheet; probed ceiling reported)
-  cpu_baseline  the CPU oracle (NumPy restatement of the reference, same einsum calls) on the
-                same inputs, on this box's host cores
+  roofline      the dominant product of the pipeline: algorithmic flops / hipEvent time per launch (bracketing
+                the fused chain-step kernel AND its slab reduce) against the fp64 MFMA peak
+  cpu_baseline  the CPU oracle (NumPy restatement of the reference, same einsum calls) on the same inputs, on
+                this box's host cores: BLAS thread sweep, T_sketch and T_total (incl. DRM sampling)
 """
 import argparse
 import ctypes
@@ -29,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 D, N_MODE, S_IN, L_RANK, R_RANK = 6, 200, 100, 50, 100
 HBM_TBS = 8.0            # TB/s, MI355X_MICROARCH.md (achievable stream rates measured here: 4.6-5.4)
-PEAK_F64_MFMA_TF = 78.6   # AMD MI355X data sheet (fp64 matrix); not listed in MI355X_MICROARCH.md
+PEAK_F64_MFMA_TF = 78.6   # AMD MI355X data sheet (fp64 matrix); profiles/scripts/mfma_probe2.hip measures 77.7 at 2.4 GHz
+METRIC = "TT-cores sketched/sec (fp64) + achieved MFMA % for d=6 n=200 r=50 stream_sketch"
 
 
 def algorithmic_flops(shape, s, l, r):
@@ -39,19 +51,14 @@ def algorithmic_flops(shape, s, l, r):
     Lr = (1,) + tuple(l)
     Rr = tuple(r) + (1,)
 
-    def chain(rk):
+    def chain(rk, S, shape):
         tot = 2 * shape[0] * S[1] * rk[1]
         for mu in range(1, d - 1):
             a, n, b, p, q = S[mu], shape[mu], S[mu + 1], rk[mu], rk[mu + 1]
             tot += min(2 * a * p * n * b + 2 * p * n * b * q, 2 * a * p * n * q + 2 * a * n * b * q)
         return tot
-    left = chain(Lr)
-    # right chain walks the transposed tensor
-    St, shp_t, Rt = S[::-1], shape[::-1], (1,) + tuple(r[::-1])
-    right = 2 * shp_t[0] * St[1] * Rt[1]
-    for mu in range(1, d - 1):
-        a, n, b, p, q = St[mu], shp_t[mu], St[mu + 1], Rt[mu], Rt[mu + 1]
-        right += min(2 * a * p * n * b + 2 * p * n * b * q, 2 * a * p * n * q + 2 * a * n * b * q)
+    left = chain(Lr, S, shape)
+    right = chain((1,) + tuple(r[::-1]), S[::-1], shape[::-1])     # the right chain walks the transposed tensor
     omega = sum(2 * l[mu] * S[mu + 1] * r[mu] for mu in range(d - 1))
     psi = 2 * shape[0] * S[1] * Rr[0] + 2 * Lr[d - 1] * S[d - 1] * shape[d - 1]
     for mu in range(1, d - 1):
@@ -61,211 +68,252 @@ def algorithmic_flops(shape, s, l, r):
 
 
 def load_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_traffic.json, written by profiles/collect_traffic.py: FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for 16-byte streaming reads on gfx950, plus WRITE_SIZE)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    entry = table.get(kernel_name)
-    return entry["bytes_per_launch"] if entry else None
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r02_traffic.json,
+    written by profiles/collect_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    streaming reads on gfx950, plus WRITE_SIZE)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                table = json.load(f)
+            for key, entry in table.items():
+                if isinstance(entry, dict) and (key == kernel_name or key.startswith(kernel_name.split("<")[0]) and kernel_name in key):
+                    return entry.get("bytes_per_launch")
+    return None
 
 
-def make_inputs(seed):
-    rng = np.random.default_rng(seed)
-    shape = (N_MODE,) * D
-    S = (1,) + (S_IN,) * (D - 1) + (1,)
-    cores = [rng.standard_normal((S[k], shape[k], S[k + 1])) / np.sqrt(S[k] * shape[k]) for k in range(D)]
-
-    def drm_cores(rank):
-        rk = (1,) + (rank,) * (D - 1)
-        return [rng.standard_normal((rk[k], N_MODE, rk[k + 1])) / np.sqrt(rk[k]) for k in range(D - 1)]
-    return shape, cores, drm_cores(L_RANK), drm_cores(R_RANK)
+def metric_name():
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f).get("metric", METRIC)
+    except (OSError, ValueError):
+        return METRIC
 
 
-def cpu_baseline(shape, cores, lcores, rcores, budget_s=12.0):
-    """Oracle (port of the reference path, same einsum strings/optimize flags) on host cores."""
+# --------------------------------------------------------------------------- CPU baseline (the oracle = "port")
+def cpu_baseline_tt(shape, cores, lcores, rcores, l_rank, r_rank, budget_s=20.0):
+    """Oracle (same einsum strings / optimize flags as the reference) on host cores: BLAS thread sweep for
+    T_sketch (DRMs pre-built, = general_sketch) and T_total (incl. DRM sampling, the reference's own timed
+    region scripts/experiment_base.py:102-113) at the best thread count."""
     import __graft_entry__ as ge
     ge.build_oracle()
     from oracle import ttsk_oracle as orc
-    ld = orc.TTDrm(lcores, shape, False)
-    rd = orc.TTDrm(rcores, shape, True)
-    orc.general_sketch("tt", cores, ld, rd, "streaming")       # warm-up
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 40):
-        t0 = time.perf_counter()
-        res = orc.general_sketch("tt", cores, ld, rd, "streaming")
-        times.append(time.perf_counter() - t0)
+    d = len(shape)
+    ld, rd = orc.TTDrm(lcores, shape, False), orc.TTDrm(rcores, shape, True)
+    res = orc.general_sketch("tt", cores, ld, rd, "streaming")       # warm-up, and the parity reference
+    import contextlib
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        maxthr = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        limit = lambda t: threadpool_limits(limits=t)
     except Exception:
-        threads = os.cpu_count() or 1
-    best = min(times)
-    return dict(value=D / best, unit="TT-cores/s", cores=int(threads), kind="port",
-                sample=f"{len(times)} sketches of the same d={D} n={N_MODE} s={S_IN} l={L_RANK} r={R_RANK} TT, "
-                       f"DRMs pre-built; best {best * 1e3:.1f} ms, median {np.median(times) * 1e3:.1f} ms",
-                ), res
+        maxthr = os.cpu_count() or 1
+        limit = lambda t: contextlib.nullcontext()
+    sweep = {}
+    counts = sorted({t for t in (8, 16, 32, 64, maxthr) if t <= maxthr})
+    per = budget_s * 0.6 / max(len(counts), 1)
+    for t in counts:
+        with limit(t):
+            times, t_end = [], time.perf_counter() + per
+            while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 12):
+                t0 = time.perf_counter()
+                orc.general_sketch("tt", cores, ld, rd, "streaming")
+                times.append(time.perf_counter() - t0)
+            sweep[t] = min(times)
+    best_t = min(sweep, key=sweep.get)
+    with limit(best_t):
+        rng = np.random.default_rng(0)
+        tot = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            l2, r2 = orc.random_tt_drm(shape, l_rank, False, rng), orc.random_tt_drm(shape, r_rank, True, rng)
+            orc.general_sketch("tt", cores, l2, r2, "streaming")
+            tot.append(time.perf_counter() - t0)
+    best = sweep[best_t]
+    return dict(value=d / best, unit="TT-cores/s", cores=int(best_t), kind="port",
+                t_sketch_ms=best * 1e3, t_total_ms_incl_drm_sampling=min(tot) * 1e3,
+                thread_sweep_ms={str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+                sample=f"general_sketch of ONE d={d} n={shape[0]} TT (DRMs pre-built) repeated per BLAS thread count "
+                       f"{counts}; best of each; T_total = DRM sampling (single NumPy stream) + sketch, best of 2"), res
 
 
-def main():
-    # dmabuf IPC is the only mode the host driver supports (RCCL between processes); must precede HIP start-up
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--batch", type=int, default=16, help="TTs per step, sketched in one batched pass (ttsk_tt_sketch_batch)")
-    ap.add_argument("--graph", type=int, default=0, help="replay the step from a hipGraph (1) or launch eagerly (0)")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="independent sketches in flight (items of the tensor stream are issued on alternating "
-                         "stream pairs); 1 = strictly one after the other")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------- helpers
+def device_tt(shape, rank, seed):
+    """Random TT generated in HBM: cores N(0,1)/sqrt(r1*n) (SURVEY 8d inputs)."""
+    from tt_sketch_amd import TensorTrain
+    from tt_sketch_amd.utils import random_normal_dev
+    S = (1,) + (rank,) * (len(shape) - 1) + (1,)
+    return TensorTrain([random_normal_dev((S[k], shape[k], S[k + 1]), seed=(seed << 8) + k, scale=1.0 / np.sqrt(S[k] * shape[k]))
+                        for k in range(len(shape))])
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
 
-    from tt_sketch_amd import _native as nat
-    from tt_sketch_amd import TensorTrain, TensorTrainDRM
-    from tt_sketch_amd.tt_fused import TTSketchPlan
-    nat.call("ttsk_init", int(os.environ.get("TTSK_BENCH_DEVICE", local_rank)))   # override: rehearsals on a one-GPU box
+def host_cores(tt):
+    return [np.asarray(c) for c in tt.cores]
 
-    dist = None
-    comm_on = world > 1 or bool(os.environ.get("TTSK_BENCH_FORCE_COMM"))   # rehearsal: the collective path with one rank
-    if world == 1 and comm_on:
-        uid = (ctypes.c_char * 128)()
-        nat.call("ttsk_comm_unique_id", uid)
-        nat.call("ttsk_comm_init", uid, 0, 1)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # host-side rendezvous only
-        uid = (ctypes.c_char * 128)()
-        if rank == 0:
-            nat.call("ttsk_comm_unique_id", uid)
-        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-        dist.broadcast(t, 0)
-        uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.numpy().tobytes()))
-        nat.call("ttsk_comm_init", uid, rank, world)
 
-    B = max(1, int(args.batch))
-    shape, cores, lcores, rcores = make_inputs(seed=3 + rank)
-    _, _, lcores, rcores = (shape, cores) + tuple(make_inputs(seed=3)[2:])   # DRMs shared by all ranks
-    all_cores = [cores] + [make_inputs(seed=3 + rank + 1000 * b)[1] for b in range(1, B)]   # B different TTs
-    tts = [TensorTrain(c) for c in all_cores]
-    tt = tts[0]
-    left = TensorTrainDRM(L_RANK, shape, False, seed=1, cores=lcores)
-    right = TensorTrainDRM(R_RANK, shape, True, seed=2, cores=rcores)
-    plan = TTSketchPlan(tt.shape, tt.rank, left, right)
-    inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
+class Job:
+    """Clock, barrier and reporting shared by the configurations."""
+
+    def __init__(self, args):
+        from tt_sketch_amd import _native as nat
+        self.nat = nat
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` for N > 1")
+            args.gpus = self.world
+        self.comm = None
+        force = bool(os.environ.get("TTSK_BENCH_FORCE_COMM"))      # rehearsal: the collective path with one rank
+        dev = os.environ.get("TTSK_BENCH_DEVICE")                  # rehearsal override on a one-GPU box
+        if self.world > 1 or force:
+            from tt_sketch_amd.distributed import RcclComm
+            self.comm = RcclComm.from_env(device=None if dev is None else int(dev))
+        else:
+            nat.call("ttsk_init", int(dev) if dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
+
+    def barrier(self):
+        if self.comm is not None:
+            self.comm.barrier()
+        else:
+            self.nat.call("ttsk_sync", -1)
+
+    def timed(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.comm is not None:
+            elapsed = self.comm.max_over_ranks(elapsed)
+        return elapsed
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+def prof_classes(nat, reps, labels):
+    classes = {}
+    for c, label in labels.items():
+        n_l, ms, flops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        nat.call("ttsk_prof_read", c, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(flops))
+        kname = ctypes.create_string_buffer(96)
+        nat.call("ttsk_prof_kernel_name", c, kname, 96)
+        if n_l.value:
+            classes[label] = dict(kernel=kname.value.decode() if c != 5 else "small_gemm_kernel / gemm_f64_kernel<...> (several)",
+                                  launches_per_step=n_l.value / reps, avg_us=1e3 * ms.value / n_l.value,
+                                  gflop_per_launch=flops.value / n_l.value * 1e-9,
+                                  tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
+                                  share_ms=ms.value / reps)
+    return classes
+
+
+# --------------------------------------------------------------------------- C3 (the headline) and its scaling modes
+def bench_c3(args, job):
+    nat = job.nat
+    from tt_sketch_amd import TensorTrainDRM
     from tt_sketch_amd.device import DevArray
+    from tt_sketch_amd.distributed import shard_bounds
+    from tt_sketch_amd.tt_fused import TTSketchPlan
+    rank, world = job.rank, job.world
+    shape = (N_MODE,) * D
+    B = max(1, int(args.batch))
+    strong = args.scaling == "strong"
+    if strong:
+        lo, hi = shard_bounds(int(args.items), rank, world)
+        n_mine = hi - lo
+        seeds = list(range(1000 + lo, 1000 + hi))
+    else:
+        n_mine = B
+        seeds = [1000 + rank * B + b for b in range(B)]
+    tts = [device_tt(shape, S_IN, s) for s in seeds]
+    left = TensorTrainDRM(L_RANK, shape, False, seed=1)            # device-sampled: identical on every rank by seed
+    right = TensorTrainDRM(R_RANK, shape, True, seed=2)
+    plan = TTSketchPlan(shape, (S_IN,) * (D - 1), left, right)
     stride = plan.size + (plan.size & 1)            # even spacing keeps every sketch 16-byte aligned
-    outs = [DevArray.empty((B * stride,)) for _ in range(inflight)]
-    out = outs[0]
-    sums = [DevArray.empty((plan.size,)) for _ in range(inflight)] if comm_on else None
-    keep, flat = [], []
-    for t in tts:
-        p1, k1 = plan.core_pointers(t)
-        keep.append(k1)
-        flat += [p1[i] for i in range(plan.d)]
-    ptrs = (ctypes.c_void_p * len(flat))(*flat)
+    passes = [(b0, min(B, n_mine - b0)) for b0 in range(0, n_mine, B)]
+    inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
+    comm_on = job.comm is not None
+    nslots = inflight if not strong else 1
+    outs = [DevArray.empty((max(n_mine, 1) * stride,)) for _ in range(nslots)]
+    sums = [DevArray.empty((plan.size,)) for _ in range(nslots)] if comm_on else None
+    keep, ptr_sets = [], []
+    for b0, cnt in passes:
+        flat = []
+        for t in tts[b0:b0 + cnt]:
+            p1, k1 = plan.core_pointers(t)
+            keep.append(k1)
+            flat += [p1[i] for i in range(plan.d)]
+        ptr_sets.append((ctypes.c_void_p * len(flat))(*flat))
     counter = [0]
+    cs = nat.NUM_STREAMS - 1                        # the one stream every collective goes to, in step order
+    P = ctypes.c_void_p
 
-    def run_on(slot):
-        plan.run_batch(ptrs, B, outs[slot], stride, stream=2 * slot)   # stream pair (2 slot, 2 slot + 1)
+    def reduce_slot(slot, first_stream):
+        """local sum of the rank's sketches, then ONE all-reduce of one sketch"""
+        nat.call("ttsk_stream_wait", cs, first_stream)
+        if n_mine == 0:
+            nat.call("ttsk_memset", P(sums[slot].ptr), 0, ctypes.c_size_t(plan.size * 8), cs)
+        elif plan.size % 2 == 0:
+            nat.call("ttsk_sum_slices", P(sums[slot].ptr), P(outs[slot].ptr), n_mine, ctypes.c_size_t(stride),
+                     ctypes.c_size_t(plan.size), 0, cs)
+        else:
+            for b in range(n_mine):
+                nat.call("ttsk_axpby", P(sums[slot].ptr), P(outs[slot].ptr + 8 * b * stride), 1.0, 1.0 if b else 0.0,
+                         ctypes.c_size_t(plan.size), cs)
+        nat.call("ttsk_comm_allreduce_sum", P(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
 
-    def step_eager():
+    def step_weak():
         slot = counter[0] % inflight
         counter[0] += 1
-        run_on(slot)
+        plan.run_batch(ptr_sets[0], B, outs[slot], stride, stream=2 * slot)      # stream pair (2 slot, 2 slot + 1)
         if comm_on:
-            # the B partial sketches of this rank are summed locally, then ONE all-reduce of one sketch
-            # (32 MB) per step makes every rank hold the sketch of the world * B term sum.  All collectives go
-            # together with the local sum to one dedicated stream in step order (no two collectives in flight on
-            # different streams of one communicator); both overlap the products of step s + 1 on the other stream pair.
-            cs = nat.NUM_STREAMS - 1
-            nat.call("ttsk_stream_wait", cs, 2 * slot)       # the step's products are queued on stream 2 slot
-            if plan.size % 2 == 0:
-                nat.call("ttsk_sum_slices", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr), B,
-                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 0, cs)
-            else:
-                for b in range(B):
-                    nat.call("ttsk_axpby", ctypes.c_void_p(sums[slot].ptr), ctypes.c_void_p(outs[slot].ptr + 8 * b * stride),
-                             1.0, 1.0 if b else 0.0, ctypes.c_size_t(plan.size), cs)
-            nat.call("ttsk_comm_allreduce_sum", ctypes.c_void_p(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
-            # this slot's streams may touch outs[slot] / sums[slot] again only after its own sum + all-reduce; the
-            # wait is queued now, so it names exactly this all-reduce and not the next step's
+            # both the local sum and the all-reduce overlap the products of step s + 1 on the other stream pair;
+            # this slot's streams touch outs / sums again only after its own all-reduce
+            reduce_slot(slot, 2 * slot)
             nat.call("ttsk_stream_wait", 2 * slot, cs)
 
-    for _ in range(inflight):
-        step_eager()
-    nat.call("ttsk_sync", -1)
-    use_graph = bool(args.graph) and not comm_on
-    graphs = []
-    if use_graph:
-        # one captured graph per in-flight slot: both chains' fork / join over the slot's stream pair
-        for slot in range(inflight):
-            g = ctypes.c_void_p()
-            nat.call("ttsk_graph_begin", 2 * slot)
-            run_on(slot)
-            nat.call("ttsk_graph_end", 2 * slot, ctypes.byref(g))
-            graphs.append(g)
+    def step_strong():
+        # the whole job: this rank's passes on alternating stream pairs, then sum + all-reduce
+        used = set()
+        for i, (b0, cnt) in enumerate(passes):
+            st = 2 * (i % inflight)
+            used.add(st)
+            plan.run_batch(ptr_sets[i], cnt, DevArray(outs[0].buf, b0 * stride, (cnt * stride,), (1,)), stride, stream=st)
+        if comm_on:
+            for st in sorted(used)[1:]:
+                nat.call("ttsk_stream_wait", sorted(used)[0] if used else 0, st)
+            reduce_slot(0, sorted(used)[0] if used else 0)
+            for st in sorted(used) or [0]:
+                nat.call("ttsk_stream_wait", st, cs)       # the next step's passes overwrite outs
 
-    def step():
-        if use_graph:
-            slot = counter[0] % inflight
-            counter[0] += 1
-            nat.call("ttsk_graph_launch", graphs[slot], 2 * slot)
-        else:
-            step_eager()
+    step = step_strong if strong else step_weak
+    elapsed = job.timed(step, args.steps, args.warmup)
+    items_per_step = int(args.items) if strong else B * world
+    value = D * items_per_step * args.steps / elapsed
 
-    def barrier():
-        nat.call("ttsk_sync", -1)
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-
-    # latency of ONE sketch issued alone (batch 1, nothing else in flight), for reference
     single_ms, api_ms, cores_per_s_r53 = None, None, None
-    if world == 1:
-        one = (ctypes.c_void_p * plan.d)(*[ptrs[i] for i in range(plan.d)])
+    if world == 1 and not strong:
+        one = (ctypes.c_void_p * plan.d)(*[ptr_sets[0][i] for i in range(plan.d)])
         for _ in range(3):
-            plan.run(one, out)
+            plan.run(one, outs[0])
         nat.call("ttsk_sync", -1)
         t1 = time.perf_counter()
         for _ in range(20):
-            plan.run(one, out)
+            plan.run(one, outs[0])
         nat.call("ttsk_sync", -1)
         single_ms = 1e3 * (time.perf_counter() - t1) / 20
         # T_total of SURVEY 8d = the reference's own timed region (scripts/experiment_base.py:102-113):
         # stream_sketch() through the Python API incl. DRM sampling, and with to_tt() on top
         import tt_sketch_amd as tsa
         api_ms = {}
-        for name, fn in (("stream_sketch", lambda: tsa.stream_sketch(tt, left_rank=L_RANK, right_rank=R_RANK)),
-                         ("stream_sketch_to_tt", lambda: tsa.stream_sketch(tt, left_rank=L_RANK, right_rank=R_RANK).to_tt())):
+        for name, fn in (("stream_sketch", lambda: tsa.stream_sketch(tts[0], left_rank=L_RANK, right_rank=R_RANK)),
+                         ("stream_sketch_to_tt", lambda: tsa.stream_sketch(tts[0], left_rank=L_RANK, right_rank=R_RANK).to_tt())):
             best = float("inf")
             for it in range(8):
                 nat.call("ttsk_sync", -1)
@@ -275,64 +323,49 @@ def main():
                 if it >= 2:
                     best = min(best, 1e3 * (time.perf_counter() - t1))
             api_ms[name] = best
-        # the reference's other oversampling choice, right rank = left + 3 ("STTA+3", scripts/plot_timings.py:110-124;
-        # SURVEY 8d asks for it next to r = 2 l): same batch, device-sampled DRM, 20 timed passes
+        # the reference's other oversampling choice, right rank = left + 3 ("STTA+3", scripts/plot_timings.py:110-124)
         r53 = L_RANK + 3
         right53 = TensorTrainDRM(r53, shape, True, seed=2)
-        plan53 = TTSketchPlan(tt.shape, tt.rank, left, right53)
+        plan53 = TTSketchPlan(shape, (S_IN,) * (D - 1), left, right53)
         stride53 = plan53.size + (plan53.size & 1)
         out53 = DevArray.empty((B * stride53,))
         for _ in range(3):
-            plan53.run_batch(ptrs, B, out53, stride53, stream=0)
+            plan53.run_batch(ptr_sets[0], B, out53, stride53, stream=0)
         nat.call("ttsk_sync", -1)
         t1 = time.perf_counter()
         for _ in range(20):
-            plan53.run_batch(ptrs, B, out53, stride53, stream=0)
+            plan53.run_batch(ptr_sets[0], B, out53, stride53, stream=0)
         nat.call("ttsk_sync", -1)
         cores_per_s_r53 = D * B * 20 / (time.perf_counter() - t1)
         del out53, plan53, right53
-        run_on(0)                      # restore the batched result checked below
-        nat.call("ttsk_sync", -1)
 
     result = None
     if rank == 0:
         fl = algorithmic_flops(shape, (S_IN,) * (D - 1), (L_RANK,) * (D - 1), (R_RANK,) * (D - 1))
-        # ---- roofline leg: per-launch device time of each GEMM class (hipEvents on the launch stream).
-        # The pass runs the same sketches on ONE stream so that the bracketed times are not inflated
-        # by the other chain's kernels sharing the CUs; they agree with rocprofv3's kernel durations.
+        # ---- roofline leg: per-launch device time of each product class (hipEvents on the launch stream).  The
+        # pass runs on ONE stream so that the bracketed times are not inflated by the other chain's kernels.
         os.environ["TTSK_SINGLE_STREAM"] = "1"
         nat.call("ttsk_sync", -1)
         nat.call("ttsk_prof_enable", 1)
         reps = max(5, min(args.steps, 50))
-        for _ in range(reps):
-            run_on(0)
+        nb0 = passes[0][1] if passes else 0
+        for _ in range(reps if nb0 else 0):
+            plan.run_batch(ptr_sets[0], nb0, outs[0], stride, stream=0)
         nat.call("ttsk_sync", -1)
-        classes = {}
-        labels = {0: "right chain GEMM1  T = R^T X^T", 1: "right chain GEMM2  R' = sum T E (split-K slabs)",
-                  2: "left chain GEMM1  T = L^T X", 3: "left chain GEMM2  L' = sum T D (split-K slabs)",
-                  4: "Psi GEMM  Psi = T R", 5: "small products (Omega, first / last mode)"}
-        for c, label in labels.items():
-            n_l, ms, flops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-            nat.call("ttsk_prof_read", c, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(flops))
-            kname = ctypes.create_string_buffer(96)
-            nat.call("ttsk_prof_kernel_name", c, kname, 96)
-            if n_l.value:
-                classes[label] = dict(kernel=kname.value.decode() if c != 5 else "gemm_f64_kernel<...> (several)",
-                                      launches_per_step=n_l.value / reps,
-                                      avg_us=1e3 * ms.value / n_l.value,
-                                      gflop_per_launch=flops.value / n_l.value * 1e-9,
-                                      tflops=flops.value / (ms.value * 1e-3) * 1e-12 if ms.value else 0.0,
-                                      share_ms=ms.value / reps)
+        labels = {0: "right chain GEMM1  T = R^T X^T (two-launch form)",
+                  1: "right chain step  R' = sum_k (X_k R) E_k  (fused: both products + slab reduce)",
+                  2: "left chain GEMM1  T = L^T X (two-launch form)",
+                  3: "left chain step  L' = sum_k (L^T X_k)^T D_k, T stored  (fused: both products + slab reduce)",
+                  4: "Psi product  Psi = T R", 5: "small products (Omega, first / last mode)"}
+        classes = prof_classes(nat, reps, labels) if nb0 else {}
         os.environ.pop("TTSK_SINGLE_STREAM", None)
         nat.call("ttsk_prof_enable", 0)
         # both roofs per class: algorithmic bytes of one launch (operands read once, result written once, the
         # shared DRM core once per launch) against HBM_TBS, flops against the matrix peak; the lower roof binds
         s_, l_, r_, n_ = S_IN, L_RANK, R_RANK, N_MODE
-        mb = {labels[0]: B * (s_ * n_ * s_ + r_ * n_ * s_) + s_ * r_ * B,
-              labels[1]: B * (r_ * n_ * s_ + s_ * r_) + r_ * n_ * r_,
-              labels[2]: B * (s_ * n_ * s_ + l_ * n_ * s_) + s_ * l_ * B,
-              labels[3]: B * (l_ * n_ * s_ + s_ * l_) + l_ * n_ * l_,
-              labels[4]: B * (l_ * n_ * s_ + l_ * n_ * r_ + s_ * r_)}
+        mb = {labels[1]: nb0 * (s_ * n_ * s_ + 2 * s_ * r_) + r_ * n_ * r_,
+              labels[3]: nb0 * (s_ * n_ * s_ + l_ * n_ * s_ + 2 * s_ * l_) + l_ * n_ * l_,
+              labels[4]: nb0 * (l_ * n_ * s_ + l_ * n_ * r_ + s_ * r_)}
         for label, doubles in mb.items():
             if label in classes:
                 c = classes[label]
@@ -342,61 +375,179 @@ def main():
                 c["roof_tflops"] = min(PEAK_F64_MFMA_TF, hbm_roof_tf)
                 c["bound"] = "hbm" if hbm_roof_tf < PEAK_F64_MFMA_TF else "mfma"
                 c["frac_of_roof"] = c["tflops"] / c["roof_tflops"]
-        dom = max(classes, key=lambda k: classes[k]["share_ms"])
-        probe = ctypes.c_double()
-        nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
-        roofline = dict(bound="mfma", kernel=classes[dom]["kernel"], what=dom, achieved=classes[dom]["tflops"], peak=PEAK_F64_MFMA_TF,
-                        unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF,
-                        traffic=load_traffic(classes[dom]["kernel"]),
-                        avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value,
-                        classes=classes,
-                        pipeline_tflops=fl["total"] * B * args.gpus * args.steps / elapsed * 1e-12)
-        cpu = None
-        parity = None
+        roofline = None
+        if classes:
+            dom = max(classes, key=lambda k: classes[k]["share_ms"])
+            probe = ctypes.c_double()
+            nat.call("ttsk_mfma_f64_peak_probe", ctypes.byref(probe))
+            roofline = dict(bound="mfma", kernel=classes[dom]["kernel"], what=dom, achieved=classes[dom]["tflops"],
+                            peak=PEAK_F64_MFMA_TF, unit="TFLOP/s", frac=classes[dom]["tflops"] / PEAK_F64_MFMA_TF,
+                            traffic=load_traffic(classes[dom]["kernel"]),
+                            algorithmic_bytes_per_launch=classes[dom].get("algorithmic_mb_per_launch", 0) * 1e6 or None,
+                            avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value, classes=classes,
+                            pipeline_tflops=fl["total"] * items_per_step * args.steps / elapsed * 1e-12)
+        cpu, parity = None, None
         if not args.no_cpu:
-            cpu, ref = cpu_baseline(shape, cores, lcores, rcores)
-            if world == 1:
-                got = out.get()[:plan.size]
-                want = np.concatenate([a.ravel() for a in ref[0] + ref[1]])
-                parity = float(np.linalg.norm(got - want) / np.linalg.norm(want))
-                if B > 1:   # the last tensor of the batch against the oracle as well
-                    import oracle.ttsk_oracle as orc
-                    ld, rd = orc.TTDrm(lcores, shape, False), orc.TTDrm(rcores, shape, True)
-                    rP, rO = orc.general_sketch("tt", all_cores[-1], ld, rd, "streaming")
+            h_cores, h_l, h_r = host_cores(tts[0]), [np.asarray(c) for c in left.cores], [np.asarray(c) for c in right.cores]
+            cpu, ref = cpu_baseline_tt(shape, h_cores, h_l, h_r, L_RANK, R_RANK)
+            if world == 1 and passes:
+                plan.run_batch(ptr_sets[0], passes[0][1], outs[0], stride, stream=0)      # the batched result checked below
+                nat.call("ttsk_sync", -1)
+                import oracle.ttsk_oracle as orc
+                ld, rd = orc.TTDrm(h_l, shape, False), orc.TTDrm(h_r, shape, True)
+                parity = 0.0
+                for b in sorted({0, passes[0][1] - 1}):                    # first and last tensor of the batch
+                    rP, rO = (ref if b == 0 else orc.general_sketch("tt", host_cores(tts[b]), ld, rd, "streaming"))
                     want = np.concatenate([a.ravel() for a in rP + rO])
-                    got = out.get()[(B - 1) * stride:(B - 1) * stride + plan.size]
+                    got = outs[0].get()[b * stride:b * stride + plan.size]
                     parity = max(parity, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
-        ms_step = 1e3 * elapsed / args.steps
-        metric = "TT-cores sketched/sec (fp64) + achieved MFMA % for d=6 n=200 r=50 stream_sketch"
-        try:
-            with open(os.path.join(ROOT, "BASELINE.json")) as f:
-                metric = json.load(f).get("metric", metric)
-        except (OSError, ValueError):
-            pass
-        result = dict(metric=metric,
-                      value=D * B * args.gpus * args.steps / elapsed, unit="TT-cores/s", n_gpus=args.gpus,
-                      steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
-                      scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                      config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / "
-                                           "right rank 100, streaming sketch (both chains, Omega, Psi), "
-                                           f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight" +
+        result = dict(metric=metric_name(), value=value, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
+                      warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                      scaling="strong" if strong else "weak", vs_baseline=None, dtype="f64", data="synthetic",
+                      config=dict(workload="TensorTrain d=6 n=200 TT-rank 100, TensorTrainDRM left rank 50 / right rank 100, "
+                                           "streaming sketch (both chains, Omega, Psi), " +
+                                           (f"fixed job of {int(args.items)} TTs dealt over the ranks, {B} per batched pass"
+                                            if strong else f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight") +
                                            ("; the rank's partial sketches are summed and ONE RCCL all-reduce of one sketch per step "
-                                            "gives every rank the sketch of the whole sum" if world > 1 else ""),
+                                            "gives every rank the sketch of the whole sum" if comm_on else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
-                                  algorithmic_gflop_per_sketch=fl["total"] * 1e-9, launch="hipGraph" if use_graph else "eager",
-                                  tts_per_step=B, steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
+                                  algorithmic_gflop_per_sketch=fl["total"] * 1e-9, tts_per_step=items_per_step,
+                                  steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
                                   t_total_ms_incl_drm_sampling=api_ms, tt_cores_per_s_right_rank_53=cores_per_s_r53,
                                   sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-    if comm_on:
-        nat.call("ttsk_comm_destroy")
-    if dist is not None:
-        dist.destroy_process_group()
     return result
 
 
+# --------------------------------------------------------------------------- C5: TensorSum of 32 rank-20 TTs
+def bench_c5(args, job):
+    nat = job.nat
+    import tt_sketch_amd as tsa
+    from tt_sketch_amd.distributed import stream_sketch_sharded
+    shape, terms, s, l, r = (128,) * 6, 32, 20, 50, 100
+    tts = [device_tt(shape, s, 500 + i) for i in range(terms)]
+    S = tsa.TensorSum(tts)
+    left = tsa.TensorTrainDRM(l, shape, False, seed=1)
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2)
+    S.prepare_device()
+
+    def step():
+        if job.comm is not None:
+            stream_sketch_sharded(S, (l,) * 5, (r,) * 5, job.comm, left_drm=left, right_drm=right)
+        else:
+            tsa.stream_sketch(S, (l,) * 5, (r,) * 5, left_drm=left, right_drm=right)
+    elapsed = job.timed(step, args.steps, args.warmup)
+    if job.rank != 0:
+        return None
+    fl = algorithmic_flops(shape, (s,) * 5, (l,) * 5, (r,) * 5)
+    gf = fl["total"] * terms
+    t_step = elapsed / args.steps
+    cpu = None
+    if not args.no_cpu:
+        cpu, _ = cpu_baseline_tt(shape, host_cores(tts[0]), [np.asarray(c) for c in left.cores],
+                                 [np.asarray(c) for c in right.cores], l, r, budget_s=12.0)
+        cpu["sample"] = "ONE of the 32 terms (the sum is 32 such sketches): " + cpu["sample"]
+    return dict(metric=metric_name(), value=6 * terms / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
+                warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="strong", vs_baseline=None,
+                dtype="f64", data="synthetic",
+                config=dict(workload="C5: stream_sketch of a TensorSum of 32 rank-20 TTs, d=6 n=128, shared TensorTrainDRMs l=50 r=100; "
+                                     "terms dealt over the ranks, one all-reduce (stream_sketch_sharded)" , terms=terms),
+                roofline=dict(bound="mfma", kernel="ttsk_tt_sketch_batch pass of the 32 terms (fused chain steps + Psi)",
+                              achieved=gf / t_step * 1e-12, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s",
+                              frac=gf / t_step * 1e-12 / PEAK_F64_MFMA_TF, traffic=None,
+                              what="algorithmic flops of the 32 term sketches (SURVEY 8d: 0.443 GF each) / wall time of one "
+                                   "stream_sketch call incl. Python and the term sum"),
+                cpu_baseline=cpu)
+
+
+# --------------------------------------------------------------------------- C2: dense d=5 n=64
+def bench_c2(args, job):
+    nat = job.nat
+    import tt_sketch_amd as tsa
+    from tt_sketch_amd.utils import random_normal_dev
+    shape, l, r = (64,) * 5, 20, 40
+    X = random_normal_dev(shape, seed=2)
+    T = tsa.DenseTensor(X)
+    left = tsa.TensorTrainDRM(l, shape, False, seed=1)
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2)
+
+    def step():
+        tsa.general_sketch(T, left, right, tsa.SketchMethod.streaming)
+    elapsed = job.timed(step, args.steps, args.warmup)
+    if job.rank != 0:
+        return None
+    t_step = elapsed / args.steps
+    one_pass, unfused, gflop = 16.77e9, 77.3e9, 484.0
+    return dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
+                warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f64", data="synthetic",
+                config=dict(workload="C2: general_sketch of a dense fp64 tensor d=5 n=64 (8.59 GB resident), TensorTrainDRM l=20 r=40"),
+                roofline=dict(bound="hbm", kernel="skinny_r_kernel / skinny_s_kernel passes over the unfoldings (5 passes over X)",
+                              achieved=one_pass / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s",
+                              frac=one_pass / t_step / (HBM_TBS * 1e12), traffic=None,
+                              what="SURVEY 8d one-pass bytes (8.59 GB tensor + 8.18 GB of DRM matrices) / wall time of one sketch",
+                              unfused_77GB_rate_gbs=unfused / t_step * 1e-9, algorithmic_tflops=gflop / t_step * 1e-3),
+                cpu_baseline=None)
+
+
+# --------------------------------------------------------------------------- C4: sparse 1e7 nnz
+def bench_c4(args, job):
+    import tt_sketch_amd as tsa
+    shape, nnz, l, r = (200, 150, 100, 120, 300), 10_000_000, 10, 15
+    rng = np.random.default_rng(4)
+    idx = np.stack([rng.integers(0, n, nnz) for n in shape]).astype(np.int64)
+    T = tsa.SparseTensor(shape, idx, rng.standard_normal(nnz))
+    left = tsa.SparseGaussianDRM(l, shape, False, seed=3)
+    right = tsa.SparseGaussianDRM(r, shape, True, seed=4)
+    T.prepare_device()
+
+    def step():
+        tsa.general_sketch(T, left, right, tsa.SketchMethod.streaming)
+    elapsed = job.timed(step, args.steps, args.warmup)
+    if job.rank != 0:
+        return None
+    t_step = elapsed / args.steps
+    nbytes, samples = 8.0 * nnz * 6, (l + r) * 4 * nnz
+    return dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
+                warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f64", data="synthetic",
+                config=dict(workload="C4: general_sketch of a COO tensor d=5 shape (200,150,100,120,300) nnz=1e7 (resident), "
+                                     "SparseGaussianDRM l=10 r=15"),
+                roofline=dict(bound="hbm", kernel="sample_rows_kernel (8 x) + sparse_psi_mfma_kernel (9 x)",
+                              achieved=nbytes / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s",
+                              frac=nbytes / t_step / (HBM_TBS * 1e12), traffic=None,
+                              what="SURVEY 8d bytes 8*nnz*(d+1) = 480 MB / wall time of one sketch; the binding unit is the "
+                                   "fp64 VALU evaluating 1e9 ndtri samples",
+                              gaussian_samples_per_s=samples / t_step),
+                cpu_baseline=None)
+
+
+def main():
+    # dmabuf IPC is the only mode the host driver supports (RCCL between processes); must precede HIP start-up
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=("c3", "c2", "c4", "c5"), default="c3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--items", type=int, default=128, help="--scaling strong: TTs in the fixed job")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--batch", type=int, default=16, help="TTs per batched pass (ttsk_tt_sketch_batch)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent passes in flight (issued on alternating stream pairs); 1 = strictly one after the other")
+    args = ap.parse_args()
+    if args.config != "c3" and args.steps == 200:
+        args.steps, args.warmup = 20, 3
+    job = Job(args)
+    try:
+        result = {"c3": bench_c3, "c2": bench_c2, "c4": bench_c4, "c5": bench_c5}[args.config](args, job)
+        if result is not None:
+            print(json.dumps(result))
+    finally:
+        job.close()            # the communicator and the rendezvous files go away on every path, failed or not
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -820,7 +820,7 @@ def test_bench_collective_path_with_one_rank():
     (1, 30, 100, 98, 100, 100, False, False),        # even / odd padding inside the strip
     (4, 40, 52, 36, 36, 40, False, True),            # 2 tiles + strip; 13 k-blocks: the run ends inside (ring padded to 15)
     (3, 33, 23, 16, 16, 20, True, False),            # one tile, K1 = 23: partial last k-block
-    (2, 25, 64, 112, 112, 112, True, True),          # 7 full tiles, 7 waves (157 KB of LDS)
+    (2, 25, 60, 112, 112, 112, True, True),          # 7 full tiles, 7 waves (154 KB of LDS), runs of 5 k-blocks
     (2, 30, 101, 70, 70, 64, False, True),           # 26 k-blocks; 4 tiles + 2 strips (6 of 8 columns valid)
     (6, 30, 100, 90, 90, 100, True, False),          # remainder 10 > 8: a zero-padded sixth tile
     (2, 20, 64, 22, 22, 30, True, True),             # 1 tile + 2 strips

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     }
     const int k_beg = (int)((int64_t)g * a.n / a.wpp), k_end = (int)((int64_t)(g + 1) * a.n / a.wpp);
     const int NW = (a.J + 15) >> 4;
-    const int KB1 = (a.K1 + 3) >> 2;
+    // k-blocks of phase A, padded to whole runs of UNR (the padded ones meet zero rows of the W image)
+    const int KB1 = ((a.K1 + 3) / 4 + UNR - 1) / UNR * UNR;
     const int AP = a.AP, A2P = a.A2P;
 
     // ---- stage W: Wl[(c >> 1) * 2 AP + 2 a + (c & 1)], zero beyond (K1, A).  A pair of k rows interleaved:
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     static_assert(UNR % D == 0, "the unrolled body must keep the ring slots static");
     // k-blocks are issued in straight-line runs of UNR (the compiler's wait counts are exact inside a run;
     // at a loop edge it waits for every load in flight); a slice is padded to whole runs
-    const int ITER = (KB1 + UNR - 1) / UNR, KBD = (KB1 + D - 1) / D * D;
+    const int ITER = KB1 / UNR;
     // fragment kb of slice k: per-lane (row, k) offset fixed, the (slice, k-block) part a scalar offset.  No
     // masks: k beyond K1 meets the zero rows of the W image, rows beyond J give output rows that are never
     // stored, a prefetch past the workgroup's last slice is unused, and whatever lies beyond the core reads
@@ -233,44 +234,30 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         };
         wfetch(Wl, 0, af, sf);
         uint32_t so = (uint32_t)k * kstep + (uint32_t)D * xstep;      // scalar offset of the next fragment to request
-        // kb = base + u with u < UNR static; the D reloads of the slice's last D k-blocks (padded to a multiple of
-        // D: KBD) are the first fragments of the next slice
-        auto kblock = [&](const double *wrun, int u, bool live, bool wrap) {
+        // k-block (run base) + u with u < UNR static; the reloads of the slice's last D k-blocks are the first
+        // fragments of the next slice
+        auto kblock = [&](const double *wrun, int u, bool wrap) {
             const int d = u % D;
             double afn[NQF ? NQF : 1], sfn[STRQ ? STRQ : 1];
-            if (live) wfetch(wrun, u + 1, afn, sfn);
+            wfetch(wrun, u + 1, afn, sfn);
             const double bf = ring[d];
-            if (live) {
 #pragma unroll
-                for (int p = 0; p < NQF; ++p) acc1[p] = mfma16(af[p], bf, acc1[p]);
+            for (int p = 0; p < NQF; ++p) acc1[p] = mfma16(af[p], bf, acc1[p]);
 #pragma unroll
-                for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
-            }
+            for (int q = 0; q < STRQ; ++q) acc1s[q] = mfma4(sf[q], bf, acc1s[q]);
             if (wrap) so = (uint32_t)(k + 1) * kstep;
             ring[d] = xload(so);
             so += xstep;
-            if (live) {
 #pragma unroll
-                for (int p = 0; p < NQF; ++p) af[p] = afn[p];
+            for (int p = 0; p < NQF; ++p) af[p] = afn[p];
 #pragma unroll
-                for (int q = 0; q < STRQ; ++q) sf[q] = sfn[q];
-            }
+            for (int q = 0; q < STRQ; ++q) sf[q] = sfn[q];
         };
-        const int FULL = KB1 / UNR;
         for (int it = 0; it < ITER; ++it) {
             const double *wrun = Wl + it * UNR * 4 * AP;
-            if (it < FULL) {
-                const bool last = (it + 1) * UNR == KBD;          // (then KB1 is a multiple of UNR)
+            const bool last = it == ITER - 1;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) kblock(wrun, u, true, last && u + D == UNR);
-            } else {
-                // the run that ends the slice inside: k-blocks up to KB1 are live, up to KBD they only keep the ring turning
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int kb = it * UNR + u;
-                    if (kb < KBD) kblock(wrun, u, kb < KB1, kb + D == KBD);
-                }
-            }
+            for (int u = 0; u < UNR; ++u) kblock(wrun, u, last && u + D == UNR);
         }
         if constexpr (WT) {
             // T[a][k][j]: register t of tile p is row a = 16 p + 4 t + kq, 16 consecutive j per row

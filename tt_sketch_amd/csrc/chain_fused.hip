@@ -4,19 +4,19 @@
 
 namespace ttsk {
 
-int launch_chain_step_a(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
-int launch_chain_step_b(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
-int launch_chain_step_c(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
-int launch_chain_step_d(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
-int launch_chain_step_e(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_a(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_b(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_c(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_d(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st);
+int launch_chain_step_e(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st);
 
-static int launch_chain_step(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st)
+static int launch_chain_step(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st)
 {
-    if (nf <= 2) return launch_chain_step_a(a, nf, str, wt, ebuf, lds, grid, st);
-    if (nf <= 4) return launch_chain_step_b(a, nf, str, wt, ebuf, lds, grid, st);
-    if (nf == 5) return launch_chain_step_c(a, nf, str, wt, ebuf, lds, grid, st);
-    if (nf == 6) return launch_chain_step_d(a, nf, str, wt, ebuf, lds, grid, st);
-    return launch_chain_step_e(a, nf, str, wt, ebuf, lds, grid, st);
+    if (nf <= 2) return launch_chain_step_a(a, nf, str, wt, ebuf, unr, lds, grid, st);
+    if (nf <= 4) return launch_chain_step_b(a, nf, str, wt, ebuf, unr, lds, grid, st);
+    if (nf == 5) return launch_chain_step_c(a, nf, str, wt, ebuf, unr, lds, grid, st);
+    if (nf == 6) return launch_chain_step_d(a, nf, str, wt, ebuf, unr, lds, grid, st);
+    return launch_chain_step_e(a, nf, str, wt, ebuf, unr, lds, grid, st);
 }
 
 static int cf_num_cu()
@@ -63,7 +63,15 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
     a.nb = c.nb; a.n = c.n; a.K1 = c.K1; a.A = c.A; a.A2 = c.A2; a.J = c.J;
     a.w_c = c.w_c; a.x_j = c.x_j; a.x_k = c.x_k; a.x_c = c.x_c; a.x_extent = c.x_extent;
     a.E = c.E;
-    const int KB1 = (c.K1 + 3) / 4, KB2 = nq * 4 + sq;                  // k-blocks of the two phases
+    // k-blocks of phase A are issued in straight-line runs of 25 or of 5 and padded to whole runs (the padded ones
+    // meet zero rows of the W image): 25 when that pads at most one k-block more than 5 does
+    const int kb = (c.K1 + 3) / 4;
+    const int pad25 = (kb + 24) / 25 * 25, pad5 = (kb + 4) / 5 * 5;
+    const int unr = pad25 <= pad5 + 1 ? 25 : 5;
+    const int KB1 = unr == 25 ? pad25 : pad5, KB2 = nq * 4 + sq;       // k-blocks of the two phases
+    // the loader brings A x A2 doubles per slice while phase A runs K1 deep: a short phase A cannot hide it, and
+    // there is little T to keep on chip anyway (the two-launch form is then the faster one: measured on C5)
+    if (mode == 1 && 2 * c.K1 < c.A) return 0;
     a.AP = 16 * nq + 4 * sq;
     a.A2P = c.A2;
     if (a.AP < 4 * KB2) return 0;
@@ -103,7 +111,7 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
     const bool prof = prof_on();
     // flops of BOTH products of the step (the pair this kernel replaces), reduce launch inside the bracket
     if (prof) prof_open(st, 2.0 * c.nb * (double)c.n * c.J * ((double)c.K1 * c.A + (double)c.A * c.A2), 6,
-                        nq * 100 + sq * 10 + (wt ? 1 : 0), false, false);
+                        nq * 100 + sq * 10 + (wt ? 1 : 0), unr == 25, false);
     static int stamps_on = [] { const char *e = getenv("TTSK_CF_STAMPS"); return e ? atoi(e) : 0; }();
     long long *stamps_dev = nullptr;
     if (stamps_on) {
@@ -111,7 +119,7 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
         (void)hipMemset(stamps_dev, 0, 8 * 8 * 8 * 8);
         a.stamps = stamps_dev;
     }
-    int rc = launch_chain_step(a, nq, sq, wt, ebuf, lds, (int)nslab, st);
+    int rc = launch_chain_step(a, nq, sq, wt, ebuf, unr, lds, (int)nslab, st);
     if (stamps_on) {
         long long h[8 * 8 * 8];
         (void)hipStreamSynchronize(st);

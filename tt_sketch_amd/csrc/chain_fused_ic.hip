@@ -4,7 +4,7 @@
 
 namespace ttsk {
 
-int launch_chain_step_c(const ChainStep &a, int nf, int str, bool wt, int ebuf, size_t lds, int grid, hipStream_t st)
+int launch_chain_step_c(const ChainStep &a, int nf, int str, bool wt, int ebuf, int unr, size_t lds, int grid, hipStream_t st)
 {
     TTSK_CF_CASE(5, 0, 1)
     TTSK_CF_CASE(5, 1, 1)

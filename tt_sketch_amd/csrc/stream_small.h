@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int x16 = lane & 15, kq = lane >> 4;
     const int prob = blockIdx.x / a.wpp, g = blockIdx.x - prob * a.wpp;
-    const int KB1 = (a.K1 + 3) >> 2, AP = a.AP;
+    const int KB1 = ((a.K1 + 3) / 4 + UNR - 1) / UNR * UNR, AP = a.AP;      // padded to whole runs: zero rows of the W image
     {
         const double *Wp = uniform_ptr(a.W[prob]);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, ((int64_t)(a.K1 - 1) * a.w_c + a.A) * 8);
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
     const uint32_t slane = (uint32_t)(((int64_t)x16 * a.s_j + kq) * 8);
     const uint32_t tstride = __builtin_amdgcn_readfirstlane((uint32_t)(16 * a.s_j * 8));
     auto sload = [&](uint32_t so) -> double { return ld8(rs, slane, __builtin_amdgcn_readfirstlane(so)); };
-    const int ITER = (KB1 + UNR - 1) / UNR, KBD = (KB1 + D - 1) / D * D;
+    const int ITER = KB1 / UNR;
     double ring[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) ring[d] = sload((uint32_t)tile * tstride + (uint32_t)d * 32u);
@@ -92,41 +92,28 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
         };
         wfetch(Wl, 0, bf, sf);
         uint32_t so = (uint32_t)tile * tstride + (uint32_t)D * 32u;
-        auto kblock = [&](const double *wrun, int u, bool live, bool wrap) {
+        auto kblock = [&](const double *wrun, int u, bool wrap) {
             const int d = u % D;
             double bfn[NF ? NF : 1], sfn[STR ? STR : 1];
-            if (live) wfetch(wrun, u + 1, bfn, sfn);
+            wfetch(wrun, u + 1, bfn, sfn);
             const double af = ring[d];
-            if (live) {
 #pragma unroll
-                for (int p = 0; p < NF; ++p) acc[p] = mfma16(af, bf[p], acc[p]);
+            for (int p = 0; p < NF; ++p) acc[p] = mfma16(af, bf[p], acc[p]);
 #pragma unroll
-                for (int q = 0; q < STR; ++q) accs[q] = mfma4(af, sf[q], accs[q]);
-            }
+            for (int q = 0; q < STR; ++q) accs[q] = mfma4(af, sf[q], accs[q]);
             if (wrap) so = (uint32_t)(tile + tstep) * tstride;       // the first fragments of this wave's next tile
             ring[d] = sload(so);
             so += 32u;
-            if (live) {
 #pragma unroll
-                for (int p = 0; p < NF; ++p) bf[p] = bfn[p];
+            for (int p = 0; p < NF; ++p) bf[p] = bfn[p];
 #pragma unroll
-                for (int q = 0; q < STR; ++q) sf[q] = sfn[q];
-            }
+            for (int q = 0; q < STR; ++q) sf[q] = sfn[q];
         };
-        const int FULL = KB1 / UNR;
         for (int it = 0; it < ITER; ++it) {
             const double *wrun = Wl + it * UNR * 4 * AP;
-            if (it < FULL) {
-                const bool last = (it + 1) * UNR == KBD;
+            const bool last = it == ITER - 1;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) kblock(wrun, u, true, last && u + D == UNR);
-            } else {
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int kb = it * UNR + u;
-                    if (kb < KBD) kblock(wrun, u, kb < KB1, kb + D == KBD);
-                }
-            }
+            for (int u = 0; u < UNR; ++u) kblock(wrun, u, last && u + D == UNR);
         }
         // register t of tile p: row 16 tile + 4 t + kq, columns 16 p .. 16 p + 15
         const int j0 = 16 * tile;

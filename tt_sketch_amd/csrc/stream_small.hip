@@ -4,10 +4,10 @@
 
 namespace ttsk {
 
-template <int NF, int STR>
+template <int NF, int STR, int UNR>
 static int launch_ss_one(const StreamSmall &a, size_t lds, int grid, hipStream_t st)
 {
-    auto kern = stream_small_kernel<NF, STR, 5, 25>;
+    auto kern = stream_small_kernel<NF, STR, 5, UNR>;
     static bool attr_done = false;
     if (!attr_done) {
         TTSK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -18,9 +18,9 @@ static int launch_ss_one(const StreamSmall &a, size_t lds, int grid, hipStream_t
     return TTSK_OK;
 }
 
-static int launch_ss(const StreamSmall &a, int nf, int str, size_t lds, int grid, hipStream_t st)
+static int launch_ss(const StreamSmall &a, int nf, int str, int unr, size_t lds, int grid, hipStream_t st)
 {
-#define TTSK_SS_CASE(NF, STR) if (nf == NF && str == STR) return launch_ss_one<NF, STR>(a, lds, grid, st);
+#define TTSK_SS_CASE(NF, STR) if (nf == NF && str == STR) return unr == 25 ? launch_ss_one<NF, STR, 25>(a, lds, grid, st) : launch_ss_one<NF, STR, 5>(a, lds, grid, st);
     TTSK_SS_CASE(1, 0) TTSK_SS_CASE(1, 1) TTSK_SS_CASE(1, 2) TTSK_SS_CASE(2, 0) TTSK_SS_CASE(2, 1) TTSK_SS_CASE(2, 2)
     TTSK_SS_CASE(3, 0) TTSK_SS_CASE(3, 1) TTSK_SS_CASE(3, 2) TTSK_SS_CASE(4, 0) TTSK_SS_CASE(4, 1) TTSK_SS_CASE(4, 2)
     TTSK_SS_CASE(5, 0) TTSK_SS_CASE(5, 1) TTSK_SS_CASE(5, 2) TTSK_SS_CASE(6, 0) TTSK_SS_CASE(6, 1) TTSK_SS_CASE(6, 2)
@@ -59,7 +59,10 @@ int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st)
     a.s_j = c.s_j; a.w_c = c.w_c; a.c_j = c.c_j;
     a.accumulate = c.accumulate;
     a.AP = 16 * nf + 4 * str;
-    const int KB1 = (c.K1 + 3) / 4;
+    const int kb = (c.K1 + 3) / 4;
+    const int pad25 = (kb + 24) / 25 * 25, pad5 = (kb + 4) / 5 * 5;
+    const int unr = pad25 <= pad5 + 1 ? 25 : 5;         // straight-line runs of k-blocks (padded to whole runs)
+    const int KB1 = unr == 25 ? pad25 : pad5;
     const size_t lds = (size_t)4 * (KB1 + 1) * a.AP * 8;
     if (lds > 160 * 1024) return 0;
     const int ntiles = (c.J + 15) / 16;
@@ -76,8 +79,8 @@ int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st)
         a.S[b] = c.S[b]; a.W[b] = c.W[b]; a.C[b] = c.C[b];
     }
     const bool prof = prof_on();
-    if (prof) prof_open(st, 2.0 * c.nb * (double)c.J * c.K1 * c.A, 7, nf * 10 + str, false, false);
-    const int rc = launch_ss(a, nf, str, lds, c.nb * wpp, st);
+    if (prof) prof_open(st, 2.0 * c.nb * (double)c.J * c.K1 * c.A, 7, nf * 10 + str, unr == 25, false);
+    const int rc = launch_ss(a, nf, str, unr, lds, c.nb * wpp, st);
     if (prof) prof_close(st);
     return rc == TTSK_OK ? 1 : (rc == 1 ? 0 : rc);
 }

@@ -36,10 +36,10 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     else if (family == 5)
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "small_gemm_kernel");
     else if (family == 7)   // streamed x small, contiguous form: tiles = 10 * full tiles + strips
-        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "stream_small_kernel<%d, %d, 5, 25>", tiles / 10, tiles % 10);
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "stream_small_kernel<%d, %d, 5, %d>", tiles / 10, tiles % 10, ak ? 25 : 5);
     else if (family == 6)   // fused chain step: tiles = 100 * full tiles + 10 * strips + (T written)
-        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "chain_step_kernel<%d, %d, %d, %d, 5, %s, 1>", tiles / 100, tiles / 10 % 10,
-                 tiles / 100, tiles / 10 % 10, tiles % 10 ? "true" : "false");
+        snprintf(g_kname[g_cls], sizeof(g_kname[0]), "chain_step_kernel<%d, %d, %d, %d, 5, %s, 1, %d, %d>", tiles / 100, tiles / 10 % 10,
+                 tiles / 100, tiles / 10 % 10, tiles % 10 ? "true" : "false", tiles / 100 <= 4 ? 2 : 1, ak ? 25 : 5);
     else if (family == 4)   // long-K: tiles = 10 * row tiles + column tiles
         snprintf(g_kname[g_cls], sizeof(g_kname[0]), "skinny_r_kernel<%d, %d, 4>", tiles / 10, tiles % 10);
     else
