@@ -581,6 +581,35 @@ def assemble(Psis, Omegas, direction="auto"):
 # --------------------------------------------------------------------------
 # helpers used by tests and the bench (not part of the reference path)
 # --------------------------------------------------------------------------
+def tt_svd(X, rank=None):
+    """tt_svd.py:10-49: left-to-right sweep, SVD of the (r n) x rest unfolding, r = max(min(cols of U, cap), 1);
+    caps trimmed as utils.py:121-175 (process_tt_rank, trim=True)."""
+    shape = X.shape
+    d = len(shape)
+    if rank is None:
+        rank = (int(np.prod(shape, dtype=np.int64)),) * (d - 1)
+    rank = tuple(rank) if not np.isscalar(rank) else (int(rank),) * (d - 1)
+    cap = list(rank)
+    for _ in range(100):                      # utils.py:121-158: sweep until the ranks are feasible
+        old = list(cap)
+        for i in range(d - 1):
+            lo = shape[i] * (cap[i - 1] if i > 0 else 1)
+            hi = shape[i + 1] * (cap[i + 1] if i < d - 2 else 1)
+            cap[i] = min(cap[i], lo, hi)
+        if cap == old:
+            break
+    cores, rest, r_prev = [], np.asarray(X, dtype=np.float64).reshape(1, -1), 1
+    for k in range(d - 1):
+        M = rest.reshape(r_prev * shape[k], -1)
+        U, S, Vt = np.linalg.svd(M, full_matrices=False)
+        r = max(min(U.shape[1], cap[k]), 1)
+        cores.append(U[:, :r].reshape(r_prev, shape[k], r))
+        rest = S[:r, None] * Vt[:r]
+        r_prev = r
+    cores.append(rest.reshape(r_prev, shape[-1], 1))
+    return cores
+
+
 def tt_to_numpy(cores):
     """tensor.py:315-321."""
     acc = cores[0].reshape(cores[0].shape[1:])

@@ -858,3 +858,73 @@ def test_fused_chain_step_against_einsum(tsa, case):
         assert rel(dO[b].get(), want[b]) < TOL, (b, rel(dO[b].get(), want[b]))
         if wt:
             assert rel(dT[b].get(), want_T[b]) < TOL, (b, rel(dT[b].get(), want_T[b]))
+
+
+def test_blocked_sketch_and_rank_increase_match_reference_runs(tsa):
+    """(f)3 on the HIP path against runs of the reference itself (tests/golden/blocked_cases.npz, generated by
+    tests/golden/make_golden_blocked.py): `blocked_stream_sketch` (sketch.py:493-525) over DRM rank slices and
+    `SketchedTensorTrain.increase_rank` (:303-353), hash DRMs rebuilt from the recorded seeds."""
+    z = np.load(os.path.join(GOLDEN, "blocked_cases.npz"))
+    meta = json.loads(str(z["meta"]))
+
+    def lists(prefix):
+        P = [z[f"{prefix}/Psi/{i}"] for i in range(sum(1 for k in z.files if k.startswith(f"{prefix}/Psi/")))]
+        O = [z[f"{prefix}/Omega/{i}"] for i in range(sum(1 for k in z.files if k.startswith(f"{prefix}/Omega/")))]
+        return P + O
+    tol = 1e-11                      # hash Gaussians agree to ULP_BAR ulp, the sums to rounding
+    for name, m in meta.items():
+        shape = tuple(m["shape"])
+        X = tsa.SparseTensor(shape, z[f"{name}/indices"], z[f"{name}/entries"])
+        if m["kind"] == "blocked":
+            cls = getattr(tsa, m["drm"])
+            left = cls(tuple(m["left_rank"]), shape, False, seed=m["left_seed"])
+            right = cls(tuple(m["right_rank"]), shape, True, seed=m["right_seed"])
+            blk = tsa.blocked_stream_sketch(X, left, right, [tuple(s) for s in m["left_slices"]],
+                                            [tuple(s) for s in m["right_slices"]])
+            for tag in ("blocked", "whole"):
+                for a, b in zip(blk.Psi_cores + blk.Omega_mats, lists(f"{name}/{tag}")):
+                    assert a.shape == b.shape and rel(a, b) < tol, (name, tag, a.shape, rel(a, b))
+        else:
+            l0, r0 = tuple(m["left_rank"]), tuple(m["right_rank"])
+            left = tsa.SparseGaussianDRM(l0, shape, False, seed=m["left_seed"])
+            right = tsa.SparseGaussianDRM(r0, shape, True, seed=m["right_seed"])
+            stt = tsa.stream_sketch(X, l0, r0, left_drm=left, right_drm=right)
+            for a, b in zip(stt.Psi_cores + stt.Omega_mats, lists(f"{name}/before")):
+                assert a.shape == b.shape and rel(a, b) < tol, (name, "before", rel(a, b))
+            stt2 = stt.increase_rank(X, tuple(m["new_left_rank"]), tuple(m["new_right_rank"]))
+            assert stt2.left_drm.seed == m["new_left_seed"] and stt2.right_drm.seed == m["new_right_seed"]
+            for tag in ("after", "direct"):
+                for a, b in zip(stt2.Psi_cores + stt2.Omega_mats, lists(f"{name}/{tag}")):
+                    assert a.shape == b.shape and rel(a, b) < tol, (name, tag, a.shape, rel(a, b))
+
+
+def test_tt_svd_on_device_matches_reference_runs(tsa):
+    """(f)4: tt_svd (reference tt_svd.py:10-49) as a device sweep -- thin QR of the transposed unfolding + Jacobi
+    SVD of the square factor -- against runs of the reference (tests/golden/tt_svd_cases.npz): identical TT
+    ranks, equal as a tensor at 1e-10, left-orthogonal cores; plus the oracle on a resident low-rank input."""
+    z = np.load(os.path.join(GOLDEN, "tt_svd_cases.npz"))
+    meta = json.loads(str(z["meta"]))
+    for name, m in meta.items():
+        X = z[f"{name}/X"]
+        ref = [z[f"{name}/core/{i}"] for i in range(len(m["shape"]))]
+        tt = tsa.tt_svd(tsa.DenseTensor(X), m["rank"])
+        assert list(tt.rank) == m["tt_rank"], (name, tt.rank)
+        cores = [np.asarray(c) for c in tt.cores]
+        assert [c.shape for c in cores] == [c.shape for c in ref]
+        assert rel(orc.tt_to_numpy(cores), orc.tt_to_numpy(ref)) < 1e-10, (name, rel(orc.tt_to_numpy(cores), orc.tt_to_numpy(ref)))
+        for c in cores[:-1]:
+            # U factors: orthonormal columns -- for the directions that carry the tensor.  Beyond the numerical
+            # rank of an unfolding (lowrank5: rank 3 under a cap of 7) LAPACK completes U arbitrarily; the Jacobi
+            # vectors there are noise / noise and multiply zero rows of the remainder (DESIGN.md, tt_svd).
+            Q = c.reshape(-1, c.shape[2])
+            G = Q.T @ Q
+            live = np.abs(np.diag(G) - 1) < 1e-8
+            assert live.sum() >= min(3, Q.shape[1]) and (name == "lowrank5" or live.all()), (name, np.diag(G))
+            assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-10, name
+    # other tensor types go through dense(); a TT input of rank 3 is recovered exactly with a generous cap
+    rng = np.random.default_rng(8)
+    cores = orc.random_tt((6, 5, 7, 4), 3, rng)
+    tt = tsa.tt_svd(tsa.TensorTrain(cores), rank=5)
+    assert list(tt.rank) == [5, 5, 4] and tt.error(tsa.TensorTrain(cores), relative=True) < 1e-10
+    want = orc.tt_svd(orc.tt_to_numpy(cores), 5)
+    assert rel(tt.to_numpy(), orc.tt_to_numpy(want)) < 1e-10

@@ -114,31 +114,6 @@ def test_read_tns(tmp_path):
         read_tns(str(zero))
 
 
-def test_tt_svd_host():
-    """tt_svd (reference tt_svd.py:10-49) is host NumPy: exact for a low-rank tensor, ranks capped and trimmed,
-    quasi-optimal truncation."""
-    from tt_sketch_amd import DenseTensor, tt_svd
-    rng = np.random.default_rng(0)
-    cores = [rng.standard_normal(s) for s in ((1, 5, 3), (3, 6, 4), (4, 7, 2), (2, 4, 1))]
-    X = cores[0].reshape(5, 3)
-    for c in cores[1:]:
-        X = np.tensordot(X, c, axes=(X.ndim - 1, 0))
-    X = X.reshape(5, 6, 7, 4)
-    tt = tt_svd(DenseTensor(X), rank=(3, 4, 2))
-    assert tt.rank == (3, 4, 2)
-    assert np.linalg.norm(tt.to_numpy() - X) < 1e-12 * np.linalg.norm(X)
-    for c in tt.cores[:-1]:
-        Q = c.reshape(-1, c.shape[2])
-        assert np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) < 1e-12
-    full = tt_svd(DenseTensor(X))
-    assert full.rank == (3, 4, 2) or all(a >= b for a, b in zip(full.rank, (3, 4, 2)))
-    Y = rng.standard_normal((5, 6, 7, 4))
-    low = tt_svd(DenseTensor(Y), rank=2)
-    assert low.rank == (2, 2, 2)
-    best1 = np.linalg.svd(Y.reshape(5, -1), compute_uv=False)
-    assert np.linalg.norm(low.to_numpy() - Y) >= np.sqrt(np.sum(best1[2:] ** 2)) - 1e-12
-
-
 def test_pool_reuse_is_stream_ordered():
     """device.py hands a released buffer out again only to the same stream, or after every stream that
     may still be touching it has been drained (cross-stream reuse)."""

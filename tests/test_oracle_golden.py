@@ -169,3 +169,74 @@ def test_structured_dense_formulas_equal_the_oracle_dense_path():
         sP, sO = st.dense_sketch_of_tt_matrices(cores, A, Bw[::-1])
         for a, b in zip(sP + sO, oP + oO):
             assert a.shape == b.shape and rel(a, b) < 1e-12, (d, a.shape, rel(a, b))
+
+
+def _blocked_fixture():
+    z = np.load(os.path.join(GOLDEN, "blocked_cases.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def _fx_lists(z, prefix):
+    P = [z[f"{prefix}/Psi/{i}"] for i in range(sum(1 for k in z.files if k.startswith(f"{prefix}/Psi/")))]
+    O = [z[f"{prefix}/Omega/{i}"] for i in range(sum(1 for k in z.files if k.startswith(f"{prefix}/Omega/")))]
+    return P, O
+
+
+def test_blocked_sketch_and_rank_increase_against_reference_fixtures():
+    """(f)3 pinned to the reference: `blocked_stream_sketch` (sketch.py:493-525) and
+    `SketchedTensorTrain.increase_rank` (:303-353) as the reference computed them with hash DRMs
+    (tests/golden/make_golden_blocked.py).  Here: the package's slicing / placement logic with the oracle as
+    the per-block sketch (the GPU twin of this test runs the HIP path)."""
+    import tt_sketch_amd as tsa
+    from tt_sketch_amd.distributed import HostComm, blocked_stream_sketch_sharded
+    from tests.test_distributed_cpu import _oracle_sketch
+    z, meta = _blocked_fixture()
+    alone = HostComm(0, 1, lambda b: b, lambda b: [b])
+    for name, m in meta.items():
+        shape = tuple(m["shape"])
+        X = tsa.SparseTensor(shape, z[f"{name}/indices"], z[f"{name}/entries"])
+        if m["kind"] == "blocked":
+            cls = getattr(tsa, m["drm"])
+            left = cls(tuple(m["left_rank"]), shape, False, seed=m["left_seed"])
+            right = cls(tuple(m["right_rank"]), shape, True, seed=m["right_seed"])
+            lsl, rsl = [tuple(s) for s in m["left_slices"]], [tuple(s) for s in m["right_slices"]]
+            if m["drm"] != "SparseGaussianDRM":
+                continue                      # the oracle stand-in below knows the Gaussian hash DRM only
+            blk = blocked_stream_sketch_sharded(X, left, right, lsl, rsl, alone, sketch_fn=_oracle_sketch)
+            for tag in ("blocked", "whole"):
+                P, O = _fx_lists(z, f"{name}/{tag}")
+                for a, b in zip(blk.Psi_cores + blk.Omega_mats, P + O):
+                    assert a.shape == b.shape and rel(a, b) < 1e-12, (name, tag, a.shape, rel(a, b))
+        else:
+            # increase_rank = blocked sketch over [0, old rank, new rank] with block (0, 0) reused
+            l0, r0 = tuple(m["left_rank"]), tuple(m["right_rank"])
+            l1, r1 = tuple(m["new_left_rank"]), tuple(m["new_right_rank"])
+            assert m["new_left_seed"] == m["left_seed"] and m["new_right_seed"] == m["right_seed"]
+            left = tsa.SparseGaussianDRM(l1, shape, False, seed=m["left_seed"])
+            right = tsa.SparseGaussianDRM(r1, shape, True, seed=m["right_seed"])
+            zeros = (0,) * (len(shape) - 1)
+            blk = blocked_stream_sketch_sharded(X, left, right, [zeros, l0, l1], [zeros, r0, r1], alone, sketch_fn=_oracle_sketch)
+            for tag in ("after", "direct"):
+                P, O = _fx_lists(z, f"{name}/{tag}")
+                for a, b in zip(blk.Psi_cores + blk.Omega_mats, P + O):
+                    assert a.shape == b.shape and rel(a, b) < 1e-12, (name, tag, a.shape, rel(a, b))
+            P0, O0 = _fx_lists(z, f"{name}/before")       # the leading block is the old sketch
+            for mu, b in enumerate(P0):
+                a = blk.Psi_cores[mu][:b.shape[0], :, :b.shape[2]]
+                assert rel(a, b) < 1e-12
+
+
+def test_oracle_tt_svd_against_reference_runs():
+    """oracle.tt_svd (checker of the device tt_svd) == the reference's tt_svd on the committed runs: same TT
+    ranks, same tensor (singular vectors are sign-free, so cores are compared through the tensor)."""
+    z = np.load(os.path.join(GOLDEN, "tt_svd_cases.npz"))
+    meta = json.loads(str(z["meta"]))
+    for name, m in meta.items():
+        X = z[f"{name}/X"]
+        ref = [z[f"{name}/core/{i}"] for i in range(len(m["shape"]))]
+        got = orc.tt_svd(X, m["rank"])
+        assert [c.shape for c in got] == [c.shape for c in ref], name
+        assert [c.shape[2] for c in got[:-1]] == m["tt_rank"]
+        assert rel(orc.tt_to_numpy(got), orc.tt_to_numpy(ref)) < 1e-12, name
+        if name in ("full3", "lowrank5"):
+            assert rel(orc.tt_to_numpy(got), X) < 1e-12          # exact when the caps do not bind
