@@ -141,9 +141,10 @@ int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const 
 /* per-kernel device timing of the launches made by ttsk_tt_sketch (bench.py roofline leg):
  * while enabled every GEMM launch is bracketed by hipEvents on its stream. */
 int ttsk_prof_enable(int on);
-/* measured ceiling of v_mfma_f64_16x16x4_f64 on this device (register-resident operands,
- * 4 independent accumulators per wave, every CU busy): TFLOP/s.  MI355X_MICROARCH.md lists
- * no fp64 MFMA row, so bench.py states this number next to the 78.6 TF/s data-sheet value. */
+/* measured ceiling of v_mfma_f64_16x16x4_f64 on this device (register-resident operands, 4 independent
+ * accumulators per wave, two waves per SIMD, every CU busy): TFLOP/s.  MI355X_MICROARCH.md lists no fp64 MFMA
+ * row, so bench.py states this number next to the 78.6 TF/s data-sheet value (it measures 77.7 at 2.4 GHz:
+ * one instruction per 64 cycles and SIMD; sustained kernels run at a lower clock). */
 int ttsk_mfma_f64_peak_probe(double *tflops);
 /* class 0/1: right-chain GEMM1 (T = R^T X^T) / GEMM2 (split-K); 2/3: left-chain GEMM1 / GEMM2;
  * 4: Psi GEMM; 5: small products (Omega, first mode); 7: untagged ttsk_gemm calls.  Only the main

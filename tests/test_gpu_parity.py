@@ -914,8 +914,8 @@ def test_tt_svd_on_device_matches_reference_runs(tsa):
         assert rel(orc.tt_to_numpy(cores), orc.tt_to_numpy(ref)) < 1e-10, (name, rel(orc.tt_to_numpy(cores), orc.tt_to_numpy(ref)))
         for c in cores[:-1]:
             # U factors: orthonormal columns -- for the directions that carry the tensor.  Beyond the numerical
-            # rank of an unfolding (lowrank5: rank 3 under a cap of 7) LAPACK completes U arbitrarily; the Jacobi
-            # vectors there are noise / noise and multiply zero rows of the remainder (tt_svd).
+            # rank of an unfolding (lowrank5: rank 3 under a cap of 7) LAPACK completes U arbitrarily; the device
+            # sweep leaves those columns zero (tt_svd.py::_inv_singular), the tensor is the same.
             Q = c.reshape(-1, c.shape[2])
             G = Q.T @ Q
             live = np.abs(np.diag(G) - 1) < 1e-8

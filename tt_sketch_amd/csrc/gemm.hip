@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(double2 *dst, const dou
     }
 }
 
-__global__ __launch_bounds__(256) void mfma_probe_kernel(double *sink, int iters, double seed)
+// 512 threads = two waves per SIMD and at most 256 registers each: with __launch_bounds__(256) hipcc parks the
+// accumulators in AGPRs and copies them in and out around every instruction (32 v_accvgpr moves + s_nop per
+// 4 matrix instructions) -- round 1's "49 TF/s ceiling of the 16x16x4 form" was that code, not the pipe.
+__global__ __launch_bounds__(512) void mfma_probe_kernel(double *sink, int iters, double seed)
 {
     v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     double x = seed + threadIdx.x * 1e-3, y = seed - threadIdx.x * 1e-3;
@@ -278,19 +281,19 @@ int ttsk_mfma_f64_peak_probe(double *tflops)
     TTSK_ARG(tflops, "ttsk_mfma_f64_peak_probe: NULL");
     double *sink = (double *)scratch(0, SCRATCH_GEMM, 1 << 16);
     if (!sink) return TTSK_ERR_HIP;
-    const int blocks = 256 * 8, iters = 2000;
+    const int blocks = 256 * 4, iters = 2000;
     hipEvent_t a, b;
     TTSK_HIP(hipEventCreate(&a));
     TTSK_HIP(hipEventCreate(&b));
     double best = 0;
     for (int rep = 0; rep < 4; ++rep) {
         TTSK_HIP(hipEventRecord(a, st));
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0 + rep);
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, st, sink, iters, 1.0 + rep);
         TTSK_HIP(hipEventRecord(b, st));
         TTSK_HIP(hipEventSynchronize(b));
         float ms = 0;
         TTSK_HIP(hipEventElapsedTime(&ms, a, b));
-        double fl = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
+        double fl = (double)blocks * 8 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
         double tf = fl / (ms * 1e-3) * 1e-12;
         if (rep > 0 && tf > best) best = tf;
     }

@@ -30,9 +30,11 @@ struct KMap {
 };
 
 // --- fp64 matrix instruction ------------------------------------------------------------
-// Measured on MI355X (scratch probes): v_mfma_f64_16x16x4_f64 peaks at 49 TF/s
-// (32 TF/s with one wave per SIMD) while v_mfma_f64_4x4x4_4b_f64 reaches 65 TF/s (58 at one
-// wave per SIMD).  The 4x4x4 form multiplies, for each of the four lane sub-groups beta
+// Measured on MI355X (profiles/scripts/mfma_probe2.hip, mfma_mix.hip): both forms reach
+// the pipe rate -- 16x16x4 one instruction per 64 cycles and SIMD (77.7 TF/s at 2.4 GHz), 4x4x4 (4 blocks) one per
+// 16-17 cycles (75 TF/s), freely mixed.  (Round 1 read 49 vs 65 TF/s off a probe compiled with
+// __launch_bounds__(256): there hipcc keeps the accumulators in AGPRs and copies them around every
+// instruction.  The same happened to this kernel until it declared two waves per SIMD.)  The 4x4x4 form multiplies, for each of the four lane sub-groups beta
 // (lanes 16k + 4 beta + {0..3}), the 4x4 blocks A[4beta+i][k] (lane 4beta+i+16k) and
 // B[k][4beta+j] (lane 4beta+j+16k) into D[4beta+i][4beta+j] at lane 16i+4beta+j, i.e. the
 // diagonal 4x4 blocks of the 16x16 product of the SAME operand registers the 16x16x4 form
@@ -192,7 +194,7 @@ __device__ __noinline__ void slow_fill(double *S, const double *__restrict__ P, 
 
 // WM x WN waves, each owning TMX x TNX MFMA tiles of 16x16 (exact, compile time).
 template <int WM, int WN, int TMX, int TNX, bool AKF, bool BKF>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(ttsk_gemm_desc d, const double *__restrict__ A,
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(ttsk_gemm_desc d, const double *__restrict__ A,
                                                        const double *__restrict__ B, double *__restrict__ C,
                                                        const double *__restrict__ kscale, int splits,
                                                        int64_t kchunk, double *__restrict__ partial,

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void sparse_psi_kernel(const double *__restric
 // slice (Omega, first / last mode) every wave would hit the same l x r addresses, so there the partial
 // sums go to `part` (one l x r block per wave) and sparse_part_reduce_kernel adds them.
 template <int TL, int TR, bool PERM>
-__global__ __launch_bounds__(256) void sparse_psi_mfma_kernel(const double *__restrict__ val, const int64_t *__restrict__ idx,
+__global__ __launch_bounds__(256, 2) void sparse_psi_mfma_kernel(const double *__restrict__ val, const int64_t *__restrict__ idx,
                                                               const int64_t *__restrict__ perm, size_t N,
                                                               const double *__restrict__ Lv, int l,
                                                               const double *__restrict__ Rv, int r, int64_t n,

@@ -29,6 +29,14 @@ from .utils import TTRank, process_tt_rank
 _SVD_MAX = 1024          # ttsk_svd_small: one workgroup, columns <= 1024
 
 
+def _inv_singular(sv: np.ndarray, m: int) -> np.ndarray:
+    """1 / sigma for the directions above the numerical rank, 0 below: there U = (U S) / S would be noise over
+    noise.  LAPACK completes U with arbitrary orthonormal vectors in that case; here those columns of the core
+    are zero (they meet rows of the remainder that are zero to rounding either way, the tensor is the same)."""
+    floor = (sv[0] if sv.size else 0.0) * 64 * np.finfo(np.float64).eps * np.sqrt(max(m, 1))
+    return np.divide(1.0, sv, out=np.zeros(sv.size), where=sv > floor)
+
+
 def _svd_wide(M: DevArray, cap: int):
     """(U_r (m, r), remainder (r, cols)) of M (m, cols) with r = max(min(min(m, cols), cap), 1)."""
     m, cols = M.shape
@@ -47,7 +55,7 @@ def _svd_wide(M: DevArray, cap: int):
         nat.call("ttsk_svd_small", P(A.ptr), m, m, P(US.ptr), P(S.ptr), P(Vt.ptr), 0)
         r = max(min(m, cap), 1)
         sv = S.get()[:r]
-        inv = DevArray.from_host(np.divide(1.0, sv, out=np.zeros(r), where=sv > 0))
+        inv = DevArray.from_host(_inv_singular(sv, m))
         eye = DevArray.from_host(np.eye(r))
         U = contract("ik,kj->ij", US[:, :r], eye, k_scale=inv)              # U_r = (U S)_r S_r^{-1}
         SVt = contract("ik,kj->ij", eye, Vt[:r], k_scale=S[:r].contiguous())  # S_r V_r^T
@@ -61,7 +69,7 @@ def _svd_wide(M: DevArray, cap: int):
     nat.call("ttsk_svd_small", P(A.ptr), m, cols, P(US.ptr), P(S.ptr), P(Vt.ptr), 0)
     r = max(min(cols, cap), 1)
     sv = S.get()[:r]
-    inv = DevArray.from_host(np.divide(1.0, sv, out=np.zeros(r), where=sv > 0))
+    inv = DevArray.from_host(_inv_singular(sv, m))
     eye = DevArray.from_host(np.eye(r))
     U = contract("ik,kj->ij", US[:, :r], eye, k_scale=inv)
     rest = contract("ik,kj->ij", eye, Vt[:r], k_scale=S[:r].contiguous())
