@@ -387,7 +387,7 @@ def bench_c3(args, job):
                             avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value, classes=classes,
                             pipeline_tflops=fl["total"] * items_per_step * args.steps / elapsed * 1e-12)
         cpu, parity = None, None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the closing barrier)
             h_cores, h_l, h_r = host_cores(tts[0]), [np.asarray(c) for c in left.cores], [np.asarray(c) for c in right.cores]
             cpu, ref = cpu_baseline_tt(shape, h_cores, h_l, h_r, L_RANK, R_RANK)
             if world == 1 and passes:
@@ -443,7 +443,7 @@ def bench_c5(args, job):
     gf = fl["total"] * terms
     t_step = elapsed / args.steps
     cpu = None
-    if not args.no_cpu:
+    if not args.no_cpu and job.world == 1:
         cpu, _ = cpu_baseline_tt(shape, host_cores(tts[0]), [np.asarray(c) for c in left.cores],
                                  [np.asarray(c) for c in right.cores], l, r, budget_s=12.0)
         cpu["sample"] = "ONE of the 32 terms (the sum is 32 such sketches): " + cpu["sample"]
@@ -533,7 +533,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--items", type=int, default=128, help="--scaling strong: TTs in the fixed job")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--batch", type=int, default=16, help="TTs per batched pass (ttsk_tt_sketch_batch)")
+    ap.add_argument("--batch", type=int, default=32, help="TTs per batched pass (ttsk_tt_sketch_batch; 32 = 8 workgroups x 25 slices per tensor in the fused chain step)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent passes in flight (issued on alternating stream pairs); 1 = strictly one after the other")
     args = ap.parse_args()
