@@ -115,13 +115,16 @@ class TensorTrainDRM(CansketchSparse, CansketchTT, CansketchCP, CanSlice, Canske
     # ------------------------------------------------------------------ dense input
     @handle_transpose
     def sketch_dense(self, tensor):
-        """The DRM as dense matrices (rho_mu, prod n_{<=mu}) (reference :109-122)."""
-        P = self._core(0).reshape(-1, self._core(0).shape[-1])
-        yield P.T
-        for mu in range(1, len(self.shape) - 1):
-            P = contract("ij,jkl->ikl", P, self._core(mu))
-            P = P.reshape(-1, P.shape[-1])
-            yield P.T
+        """The DRM as dense matrices (rho_mu, prod n_{<=mu}) (reference :109-122).
+
+        Handed out as ``ChainedUnfolding`` recipes (P_k = P_{k-1} x D_k): the dense Omega / Psi routines
+        contract the tensor one mode at a time and never form the (rho x n^k) matrices; anything else that
+        touches one gets the matrix (``as_dev`` / ``np.asarray`` / ``.get()`` materialise it)."""
+        from ..sketching_methods.dense_sketch import ChainedUnfolding
+        P = None
+        for mu in range(len(self.shape) - 1):
+            P = ChainedUnfolding(P, self._core(mu))
+            yield P
 
     # ------------------------------------------------------------------ Tucker input
     @handle_transpose

@@ -1,57 +1,175 @@
 """Omega / Psi for dense inputs (reference ``dense_sketch.py:7-52``): DRM matrices applied to
 C-order unfoldings of the tensor, which are zero-copy reshapes of the resident array.
 
+Generic DRM matrices (``DenseGaussianDRM``, user plug-ins):
 ``Omega_mu = (A_mu X^{<mu+1>}) B_mu^T`` and ``Psi_{mu+1} = (A_mu X^{<mu+1>}) x B_{mu+1}^T`` start with
 the same product -- the one full pass over the tensor.  The reference recomputes it; here it is kept
 for the duration of one ``general_sketch`` (5 instead of 9 passes over X for d = 5).
+
+``TensorTrainDRM`` hands out recipes (``ChainedUnfolding``) instead of matrices.  Left: A_mu = A_{mu-1} x D_mu,
+so ``Z_mu = A_mu X^{<mu+1>}`` follows from ``Z_{mu-1}`` by contracting one mode with one core -- only ``Z_0``
+reads the tensor, the (rho x n^mu) matrices are never formed -- and
+``Omega_mu[p, m] = sum_{i,k} D_mu[i, k, p] Psi_mu[i, k, m]`` needs no pass at all.  Right: see
+``_right_product``.  Two passes over X remain (Z_0 and Psi_0) and two over Z_0 (rho/n of X each), no
+matrix larger than n^{d-2} x rho exists; same numbers as the reference up to the order of summation
+(tests: golden fixtures at 1e-12, C2 at full size).
 """
 import numpy as np
 
-from ..device import as_dev, contract
+from ..device import DevArray, as_dev, contract
 
-_shared = {}     # key -> (A, X, A X^{<mu+1>}); cleared by general_sketch_device
+_shared = {}     # key -> (objects the key's ids refer to ..., product); cleared by general_sketch_device
 
 
 def clear_shared() -> None:
     _shared.clear()
 
 
+class ChainedUnfolding:
+    """The sketching matrix (rho_mu x n_0...n_mu) of a TensorTrainDRM after mu + 1 modes of the (for a right
+    DRM: transposed) tensor, as a recipe: the previous recipe and the core D_mu (rho_{mu-1}, n_mu, rho_mu)
+    (reference tensor_train_drm.py:109-122 forms the matrix).  ``materialise`` / ``get`` / ``np.asarray``
+    give the matrix the reference yields."""
+
+    def __init__(self, prev, core: DevArray):
+        self.prev, self.core = prev, core
+        self.depth = 0 if prev is None else prev.depth + 1
+        self.shape = (core.shape[2], core.shape[1] * (1 if prev is None else prev.shape[1]))
+        self._P = None          # (n_0...n_mu, rho_mu), contiguous
+
+    def _rows(self) -> DevArray:
+        if self._P is None:
+            if self.prev is None:
+                self._P = self.core.reshape(-1, self.core.shape[-1])
+            else:
+                P = contract("ij,jkl->ikl", self.prev._rows(), self.core)
+                self._P = P.reshape(-1, P.shape[-1])
+        return self._P
+
+    def materialise(self) -> DevArray:
+        return self._rows().T
+
+    def get(self) -> np.ndarray:
+        return self.materialise().get()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
+
+
 def _unfold(X, k):
     return X.reshape(int(np.prod(X.shape[:k], dtype=np.int64)), -1)
 
 
+def _norm(x):
+    """None and recipes as they are; anything else as a device matrix."""
+    return x if x is None or isinstance(x, ChainedUnfolding) else as_dev(x)
+
+
+def _mat(x) -> DevArray:
+    return x.materialise() if isinstance(x, ChainedUnfolding) else x
+
+
+def _ident(x):
+    """What identifies a sketching matrix for the lifetime of one general_sketch."""
+    if x is None or isinstance(x, ChainedUnfolding):
+        return id(x)
+    return (id(x.buf), x.offset, x.shape, x.strides)
+
+
 def _left_product(A, X, mu):
     """A X^{<mu+1>}, (l, prod n_{>mu}); A is the left sketch of modes 0..mu."""
-    key = (id(A.buf), A.offset, A.shape, A.strides, id(X.buf), X.offset, mu)
+    key = ("left", _ident(A), id(X.buf), X.offset, mu)
     hit = _shared.get(key)
     if hit is None:
-        hit = _shared[key] = (A, X, contract("ip,pq->iq", A, _unfold(X, mu + 1)))
+        if not isinstance(A, ChainedUnfolding):
+            Z = contract("ip,pq->iq", A, _unfold(X, mu + 1))
+        elif A.prev is None:
+            Z = contract("kp,kq->pq", A.core[0], _unfold(X, 1))             # the one pass over X
+        else:
+            rho, n, _ = A.core.shape
+            Zp = _left_product(A.prev, X, mu - 1).reshape(rho, n, -1)
+            step = max(1, 128 // n)
+            if Zp.shape[2] >= 8192 and n <= 128 and rho > step:
+                # contracted extent rho*n in slices of <= 128: the streaming small-K kernel with an
+                # accumulating output (3.5 TB/s) instead of the generic tiles (1.1 TB/s at rho*n = 1280)
+                Z = None
+                for j0 in range(0, rho, step):
+                    Z = contract("jkp,jkq->pq", A.core[j0:j0 + step], Zp[j0:j0 + step], out=Z,
+                                 accumulate=Z is not None)
+            else:
+                Z = contract("jkp,jkq->pq", A.core, Zp)
+        hit = _shared[key] = (A, X, Z)
     return hit[2]
+
+
+def _right_product(S: DevArray, B) -> DevArray:
+    """S B^T for a (rows, cols) view S of the tensor or of a left product and the right sketch B (r, cols).
+
+    The reference pairs B's columns with S's position by position, and a TensorTrainDRM's matrix is
+    B[m, (q, t)] = sum_p P[q, p] D[p, t, m] with P the matrix of one core less (tensor_train_drm.py:109-122
+    on the transposed tensor), t the LAST mode of S's columns.  So
+    S B^T = (sum_q S[b, q, t] P[q, p]) x D: one streamed pass with an (n^{k-1} x rho) matrix instead of
+    the (n^k x r) one -- for Psi_0 of C2 84 MB next to the tensor instead of 5.4 GB, and no product to
+    form it."""
+    if isinstance(B, ChainedUnfolding) and B.prev is not None:
+        rho, t, r = B.core.shape
+        rows, cols = S.shape
+        q = cols // t
+        if q * r > rows * rho:
+            U = contract("qp,bqt->bpt", B.prev._rows(), S.reshape(rows, q, t))
+            return contract("bpt,ptm->bm", U, B.core)
+    return contract("bq,mq->bm", S, _mat(B))
+
+
+def _psi_chained(Aprev, B, X, mu, keep=True):
+    """Psi_mu (rho_{mu-1}, n_mu, r_mu) for a chained left sketch; computed once per (left, right, mu)."""
+    key = ("psi", _ident(Aprev), _ident(B), id(X.buf), X.offset, mu)
+    hit = _shared.get(key) if keep else _shared.pop(key, None)
+    if hit is not None:
+        return hit[-1]
+    if Aprev is None:
+        P = _right_product(_unfold(X, 1), B)[None]
+    else:
+        Z = _left_product(Aprev, X, mu - 1)
+        if B is None:
+            P = Z[:, :, None]
+        else:
+            rho, n = Z.shape[0], X.shape[mu]
+            P = _right_product(Z.reshape(rho * n, -1), B).reshape(rho, n, -1)
+    if keep:
+        _shared[key] = (Aprev, B, X, P)
+    return P
 
 
 def sketch_omega_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
     """Omega_mu = A_mu X^{<mu+1>} B_mu^T."""
     X = tensor.dev_data()
-    A, B = as_dev(left_sketch), as_dev(right_sketch)
+    A, B = _norm(left_sketch), _norm(right_sketch)
+    if isinstance(A, ChainedUnfolding) and A.depth == mu:
+        Psi = _psi_chained(A.prev, B, X, mu)
+        return contract("ikp,ikm->pm", A.core, Psi)
+    A = _mat(A)
     if A.shape[0] <= B.shape[0]:
-        return contract("iq,jq->ij", _left_product(A, X, mu), B)
-    return contract("ip,pj->ij", A, contract("pq,jq->pj", _unfold(X, mu + 1), B))
+        return _right_product(_left_product(A, X, mu), B)
+    return contract("ip,pj->ij", A, _right_product(_unfold(X, mu + 1), B))
 
 
 def sketch_psi_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
     X = tensor.dev_data()
     d = X.ndim
-    if left_sketch is None:
-        return contract("kq,mq->km", _unfold(X, 1), as_dev(right_sketch))[None]
-    if right_sketch is None:
-        return contract("ip,pk->ik", as_dev(left_sketch), _unfold(X, d - 1))[:, :, None]
-    A, B = as_dev(left_sketch), as_dev(right_sketch)
+    A, B = _norm(left_sketch), _norm(right_sketch)
+    if A is None or (isinstance(A, ChainedUnfolding) and A.depth == mu - 1):
+        # (Psi_0 is shared with Omega_0 of a chained left sketch, which asked for it first)
+        return _psi_chained(A, B, X, mu, keep=False)
+    A = _mat(A)
+    if B is None:
+        return contract("ip,pk->ik", A, _unfold(X, d - 1))[:, :, None]
     J = int(np.prod(X.shape[:mu], dtype=np.int64))
-    X3 = X.reshape(J, X.shape[mu], -1)
-    K, Lr = X3.shape[1], X3.shape[2]
+    K, Lr = X.shape[mu], int(np.prod(X.shape[mu + 1:], dtype=np.int64))
     l, r = A.shape[0], B.shape[0]
-    key = (id(A.buf), A.offset, A.shape, A.strides, id(X.buf), X.offset, mu - 1)
+    key = ("left", _ident(A), id(X.buf), X.offset, mu - 1)
     if key in _shared or l * J * K * Lr + l * K * Lr * r <= J * K * Lr * r + l * J * K * r:
-        T = _left_product(A, X, mu - 1).reshape(l, K, Lr)       # shared with Omega_{mu-1}
-        return contract("ikl,ml->ikm", T, B)
-    return contract("ij,jkm->ikm", A, contract("jkl,ml->jkm", X3, B))
+        T = _left_product(A, X, mu - 1)                          # shared with Omega_{mu-1}
+        return _right_product(T.reshape(l * K, Lr), B).reshape(l, K, r)
+    return contract("ij,jkm->ikm", A, _right_product(X.reshape(J * K, Lr), B).reshape(J, K, r))
