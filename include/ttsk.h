@@ -221,9 +221,10 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
 int ttsk_pinv_begin(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv, int stream);
 int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
                   int *host_rank /* may be NULL */, int stream);
-/* thin SVD of a small matrix (TensorTrain.round, tensor.py:446-484, after a QR has reduced the
- * unfolding to its triangular factor): A (m, n) row-major, m >= n, n <= 1024, by one-sided Jacobi in
- * one workgroup.  US (m, n) = U diag(S), S (n) descending, Vt (n, n); A = US Vt. */
+/* thin SVD of a small matrix (TensorTrain.round, tensor.py:446-484, and tt_svd.py:21-42, after a QR has
+ * reduced the unfolding to its triangular factor): A (m, n) row-major, m >= n, by one-sided Jacobi --
+ * n <= 1024 in one workgroup (asynchronous), 1024 < n <= 8192 over all compute units with a grid barrier
+ * per round (blocks the host once).  US (m, n) = U diag(S), S (n) descending, Vt (n, n); A = US Vt. */
 int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,
                    int stream);
 /* zero the strictly lower triangle of A (m, n) row-major: the triangular factor R = Q^T M of a thin

@@ -928,3 +928,44 @@ def test_tt_svd_on_device_matches_reference_runs(tsa):
     assert list(tt.rank) == [5, 5, 4] and tt.error(tsa.TensorTrain(cores), relative=True) < 1e-10
     want = orc.tt_svd(orc.tt_to_numpy(cores), 5)
     assert rel(tt.to_numpy(), orc.tt_to_numpy(want)) < 1e-10
+
+
+def test_jacobi_svd_over_the_whole_chip(tsa):
+    """ttsk_svd_small beyond one workgroup (n > 1024: svd_grid.hip, a grid barrier per Jacobi round) against
+    LAPACK: singular values at 1e-12 of the largest, A = US Vt, orthogonal factors; full rank and rank 40."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(31)
+    P = ctypes.c_void_p
+    for m, n, rank in ((1300, 1100, None), (1100, 1100, 40), (2300, 1030, None)):
+        A = rng.standard_normal((m, n))
+        if rank:
+            A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
+        dA = DevArray.from_host(A)
+        US, S, Vt = DevArray.empty((m, n)), DevArray.empty((n,)), DevArray.empty((n, n))
+        nat.call("ttsk_svd_small", P(dA.ptr), m, n, P(US.ptr), P(S.ptr), P(Vt.ptr), 0)
+        us, s, vt = US.get(), S.get(), Vt.get()
+        want = np.linalg.svd(A, compute_uv=False)
+        assert np.all(np.diff(s) <= 0)
+        assert np.max(np.abs(s - want)) < 1e-12 * want[0], (m, n, np.max(np.abs(s - want)) / want[0])
+        assert rel(us @ vt, A) < 1e-12, (m, n, rel(us @ vt, A))
+        assert np.max(np.abs(vt @ vt.T - np.eye(n))) < 1e-12
+        k = rank or n
+        U = us[:, :k] / s[:k]
+        assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-10, (m, n)
+
+
+def test_tt_svd_with_an_unfolding_beyond_one_workgroup(tsa):
+    """tt_svd where r n = 36 x 36 = 1296 rows meet 1920 columns: QR of the transpose, then the 1296 x 1296
+    factor on the whole-chip Jacobi kernel.  Against the oracle's restatement of reference tt_svd.py:10-49."""
+    rng = np.random.default_rng(32)
+    shape = (36, 36, 48, 40)
+    X = orc.tt_to_numpy(orc.random_tt(shape, 9, rng)) + 1e-3 * rng.standard_normal(shape)
+    tt = tsa.tt_svd(tsa.DenseTensor(X), rank=(36, 40, 30))
+    want = orc.tt_svd(X, (36, 40, 30))
+    assert list(tt.rank) == [c.shape[2] for c in want[:-1]] == [36, 40, 30]
+    assert rel(tt.to_numpy(), orc.tt_to_numpy(want)) < 1e-10
+    for c in tt.cores[:-1]:
+        Q = np.asarray(c).reshape(-1, c.shape[2])
+        assert np.max(np.abs(Q.T @ Q - np.eye(Q.shape[1]))) < 1e-10

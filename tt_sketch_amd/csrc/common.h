@@ -54,6 +54,9 @@ bool prof_on();
 void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, bool bk);
 void prof_close(hipStream_t st);
 
+// svd_grid.hip: one-sided Jacobi SVD over all compute units (n beyond the one-workgroup kernel)
+int svd_jacobi_grid(const double *A, int64_t m, int64_t n, double *US, double *S, double *Vt, int stream, hipStream_t st);
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace ttsk

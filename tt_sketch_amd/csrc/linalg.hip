@@ -715,8 +715,12 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(dev_A && dev_US && dev_S && dev_Vt, "ttsk_svd_small: NULL argument");
-    TTSK_ARG(m >= n && n >= 1 && n <= 1024, "ttsk_svd_small: need m >= n, 1 <= n <= 1024, got (%lld, %lld)",
+    TTSK_ARG(m >= n && n >= 1 && n <= 8192 && m <= (1 << 20), "ttsk_svd_small: need m >= n, 1 <= n <= 8192, got (%lld, %lld)",
              (long long)m, (long long)n);
+    // beyond one workgroup's reach (or from TTSK_SVD_GRID_FROM columns on: tests): the whole-chip kernel of svd_grid.hip
+    static const int64_t grid_from = [] { const char *e = getenv("TTSK_SVD_GRID_FROM"); return e ? atoll(e) : 1025ll; }();
+    if (n >= grid_from) return svd_jacobi_grid(dev_A, m, n, dev_US, dev_S, dev_Vt, stream, st);
+    TTSK_ARG(n <= 1024, "ttsk_svd_small: the one-workgroup kernel takes n <= 1024");
     double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(m * n + n * n) * 8);
     if (!ws) return TTSK_ERR_HIP;
     size_t jl = 0;

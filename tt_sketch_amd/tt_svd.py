@@ -4,7 +4,8 @@ Left-to-right sweep over the C-order unfoldings ``M_mu`` (``r_{mu-1} n_mu`` x re
 The reference takes a LAPACK SVD of every (usually very wide) unfolding; here
 
     M^T = Q R            thin QR of the tall transpose (``ttsk_qr_thin``: CholeskyQR2 / Householder)
-    R^T = U S V^T        one-sided Jacobi SVD of the small square factor (``ttsk_svd_small``, one workgroup)
+    R^T = U S V^T        one-sided Jacobi SVD of the small square factor (``ttsk_svd_small``: one workgroup up
+                         to m = 1024, all compute units with a barrier per round up to 8192)
     core_mu   = U[:, :r]                       r = max(min(#columns, rank cap), 1), reference :23, :35
     remainder = S_r V_r^T Q^T  (= U_r^T M)     carried to the next mode, reference :29-31, :38-42
 
@@ -26,7 +27,7 @@ from .device import DevArray, contract, copy_into
 from .tensor import Tensor, TensorTrain
 from .utils import TTRank, process_tt_rank
 
-_SVD_MAX = 1024          # ttsk_svd_small: one workgroup, columns <= 1024
+_SVD_MAX = 8192          # ttsk_svd_small: one workgroup up to 1024 columns, the whole chip (svd_grid.hip) beyond
 
 
 def _inv_singular(sv: np.ndarray, m: int) -> np.ndarray:
@@ -43,7 +44,7 @@ def _svd_wide(M: DevArray, cap: int):
     P = ctypes.c_void_p
     if cols >= m:
         if m > _SVD_MAX:
-            raise ValueError(f"tt_svd: unfolding with {m} rows is beyond the one-workgroup SVD (<= {_SVD_MAX}); "
+            raise ValueError(f"tt_svd: unfolding with {m} rows is beyond the Jacobi SVD (<= {_SVD_MAX}); "
                              "lower the rank cap of the previous mode")
         Q = DevArray.empty((cols, m))
         copy_into(Q, M.T)                                       # M^T, tall
@@ -63,7 +64,7 @@ def _svd_wide(M: DevArray, cap: int):
         return U, rest
     # tall unfolding (the last modes of a sweep with generous caps): M = U S V^T directly
     if cols > _SVD_MAX:
-        raise ValueError(f"tt_svd: tall unfolding with {cols} columns is beyond the one-workgroup SVD (<= {_SVD_MAX})")
+        raise ValueError(f"tt_svd: tall unfolding with {cols} columns is beyond the Jacobi SVD (<= {_SVD_MAX})")
     A = M.contiguous()
     US, S, Vt = DevArray.empty((m, cols)), DevArray.empty((cols,)), DevArray.empty((cols, cols))
     nat.call("ttsk_svd_small", P(A.ptr), m, cols, P(US.ptr), P(S.ptr), P(Vt.ptr), 0)
