@@ -86,7 +86,8 @@ int ttsk_copy_strided(double *dst, const double *src, int ndim, const int64_t *s
  * (sketch_container.py:61-69) and the TensorSum accumulators (sketch_dispatch.py:93-136) */
 int ttsk_axpby(double *y, const double *x, double a, double b, size_t n, int stream);
 /* dst[i] (+)= sum_{b<nb} src[b*stride + i], i < n: the partial sketches of a batch summed into one
- * (the `+=` loop of sum_sketch, sketch_dispatch.py:141-147); n, stride even, 16-byte aligned bases */
+ * (the `+=` loop of sum_sketch, sketch_dispatch.py:141-147); 16-byte loads when n and stride are even and the
+ * bases 16-byte aligned */
 int ttsk_sum_slices(double *dst, const double *src, int nb, size_t stride, size_t n, int accumulate, int stream);
 
 /* ---- TT input x TT DRMs: the whole streaming sketch in one call ---------------
@@ -123,6 +124,14 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                          const double *const *X, const double *const *DL, const double *const *DR,
                          double *out, int64_t out_stride, int accumulate, int stream);
+/* The sketch of the SUM of nb tensors of one signature (a TensorSum of TTs, sketch_dispatch.py:85-139) as ONE
+ * packed sketch at `out`: the chains run per tensor as in ttsk_tt_sketch_batch, Psi_mu and Omega_mu contract over
+ * (tensor, TT rank) in one product each -- a sum of TTs is a TT with block-diagonal cores -- so no per-tensor
+ * sketch is written or summed.  accumulate != 0 adds to `out`. */
+int ttsk_tt_sketch_sum(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                       const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                       const double *const *X, const double *const *DL, const double *const *DR,
+                       double *out, int accumulate, int stream);
 /* One interior step of a TensorTrainDRM chain for nb tensors of one signature, both products in one launch
  * with the intermediate kept on chip (csrc/chain_fused.h):
  *   Out_b[j, a'] = sum_{c, a, k} W_b[c, a] X_b(j, k, c) E[a, k, a']        (tensor_train_drm.py:81-87)

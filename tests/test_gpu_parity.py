@@ -558,9 +558,14 @@ def test_sum_slices(tsa):
         nat.call("ttsk_sum_slices", ctypes.c_void_p(d.ptr), ctypes.c_void_p(s_.ptr), nb, ctypes.c_size_t(stride),
                  ctypes.c_size_t(n), acc, 0)
         assert rel(d.get(), want + acc * dst0) < 1e-15
-    with pytest.raises(ValueError):
-        nat.call("ttsk_sum_slices", ctypes.c_void_p(d.ptr), ctypes.c_void_p(s_.ptr), nb, ctypes.c_size_t(stride),
-                 ctypes.c_size_t(n - 1), 0, 0)
+    # odd length / odd stride / a base that is only 8-byte aligned: the scalar variant
+    for n2, stride2, shift in ((n - 1, stride, 0), (n, stride - 1, 0), (n - 2, stride, 1)):
+        d, s_ = DevArray.from_host(dst0), DevArray.from_host(src)
+        nat.call("ttsk_sum_slices", ctypes.c_void_p(d.ptr), ctypes.c_void_p(s_.ptr + 8 * shift), nb,
+                 ctypes.c_size_t(stride2), ctypes.c_size_t(n2), 1, 0)
+        want2 = dst0[:n2] + sum(src[shift + b * stride2:shift + b * stride2 + n2] for b in range(nb))
+        got = d.get()
+        assert rel(got[:n2], want2) < 1e-15 and np.array_equal(got[n2:], dst0[n2:])
 
 
 def test_batched_one_call_path(tsa):

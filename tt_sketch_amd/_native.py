@@ -59,6 +59,7 @@ def _bind(lib):
         "ttsk_sum_slices": [P, P, I, S, S, I, I],
         "ttsk_tt_sketch": [I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
         "ttsk_tt_sketch_batch": [I, I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, c_int64, I, I],
+        "ttsk_tt_sketch_sum": [I, I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
         "ttsk_chain_step": [I, I, I, I, I, I, POINTER(P), c_int64, POINTER(P), c_int64, c_int64, c_int64, c_int64, P,
                             POINTER(P), POINTER(P), I],
         "ttsk_prof_enable": [I],
@@ -134,12 +135,12 @@ _dirty = set()
 # entry points whose LAST argument is the library stream their work is queued on
 _STREAM_LAST = frozenset((
     "ttsk_memset", "ttsk_d2d", "ttsk_gemm", "ttsk_copy_strided", "ttsk_axpby", "ttsk_sum_slices",
-    "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_chain_step", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
+    "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
     "ttsk_fill_normal", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
     "ttsk_sparse_sort_mode", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
     "ttsk_qr_thin", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
 _BLOCKING = frozenset(("ttsk_h2d", "ttsk_d2h"))          # return only after their stream has drained
-_TWO_STREAMS = frozenset(("ttsk_tt_sketch", "ttsk_tt_sketch_batch"))   # fork a helper on stream + 1, joined back
+_TWO_STREAMS = frozenset(("ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum"))   # fork a helper on stream + 1, joined back
 
 
 def sync_epoch() -> int:

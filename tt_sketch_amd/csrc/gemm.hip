@@ -116,6 +116,17 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(double2 *dst, const dou
     }
 }
 
+// the same for odd lengths / strides or bases that are not 16-byte aligned
+__global__ __launch_bounds__(256) void sum_slices_scalar_kernel(double *dst, const double *src, int nb, size_t stride, size_t n,
+                                                                int accumulate)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double acc = accumulate ? dst[i] : 0.0;
+        for (int b = 0; b < nb; ++b) acc += src[(size_t)b * stride + i];
+        dst[i] = acc;
+    }
+}
+
 // 512 threads = two waves per SIMD and at most 256 registers each: with __launch_bounds__(256) hipcc parks the
 // accumulators in AGPRs and copies them in and out around every instruction (32 v_accvgpr moves + s_nop per
 // 4 matrix instructions) -- round 1's "49 TF/s ceiling of the 16x16x4 form" was that code, not the pipe.
@@ -336,9 +347,14 @@ int ttsk_sum_slices(double *dst, const double *src, int nb, size_t stride, size_
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(dst && src && nb >= 1, "ttsk_sum_slices: bad argument");
-    TTSK_ARG(!(n & 1) && !(stride & 1) && !(((uintptr_t)dst | (uintptr_t)src) & 15),
-             "ttsk_sum_slices: length, stride and bases must be even / 16-byte aligned");
     if (n == 0) return TTSK_OK;
+    if ((n & 1) || (stride & 1) || (((uintptr_t)dst | (uintptr_t)src) & 15)) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sum_slices_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, nb, stride, n, accumulate);
+        TTSK_LAUNCH_CHECK();
+        return TTSK_OK;
+    }
     size_t blocks = (n / 2 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (double2 *)dst, (const double2 *)src,

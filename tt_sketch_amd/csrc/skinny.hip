@@ -240,10 +240,12 @@ int skinny_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, co
     if (K > 128 || K < 1) return 0;
     // which side streams?  A batch index joins the streamed index when the small operand is shared
     // by the batch and the output is contiguous across it (right chain GEMM1: b = k, n = p'').
-    const bool a_small = d.M <= 128 && d.batch * d.N >= 2048 && d.M <= d.N &&
-                         (d.batch == 1 || (d.a_b == 0 && d.c_b >= 0));
-    const bool b_small = !a_small && d.N <= 128 && d.batch * d.M >= 2048 &&
-                         (d.batch == 1 || (d.b_b == 0 && d.c_b >= 0));
+    // (when both sides could play the small operand the smaller one does; a batched product whose larger side
+    // is the shared one -- T[q,k,b,p''] of tt_fused.hip with few p'' -- still goes here, with that side small)
+    const bool a_ok = d.M <= 128 && d.batch * d.N >= 2048 && (d.batch == 1 || (d.a_b == 0 && d.c_b >= 0));
+    const bool b_ok = d.N <= 128 && d.batch * d.M >= 2048 && (d.batch == 1 || (d.b_b == 0 && d.c_b >= 0));
+    const bool a_small = a_ok && (d.M <= d.N || !b_ok);
+    const bool b_small = !a_small && b_ok;
     if (!a_small && !b_small) return 0;
     SkinnyS s{};
     s.nb = nb;

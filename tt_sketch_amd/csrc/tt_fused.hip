@@ -183,10 +183,35 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
     return ttsk_tt_sketch_batch(1, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X, DL, DR, out, 0, accumulate, stream);
 }
 
+static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                          const double *const *X, const double *const *DL, const double *const *DR, double *out,
+                          int64_t out_stride, int accumulate, int stream, bool sum);
+
 int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                          const double *const *X, const double *const *DL, const double *const *DR, double *out,
                          int64_t out_stride, int accumulate, int stream)
+{
+    return tt_sketch_core(nb, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X, DL, DR, out, out_stride, accumulate, stream, false);
+}
+
+int ttsk_tt_sketch_sum(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                       const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                       const double *const *X, const double *const *DL, const double *const *DR, double *out,
+                       int accumulate, int stream)
+{
+    return tt_sketch_core(nb, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X, DL, DR, out, 0, accumulate, stream, true);
+}
+
+// sum = false: sketch b at out + b * out_stride.  sum = true: ONE sketch, of the sum of the nb tensors -- the chains
+// run per tensor as before (a sum of TTs is a TT with block-diagonal cores), Psi and Omega contract over
+// (tensor, rank) at once: the per-tensor workspaces are equally spaced, so that pair is a two-level contracted
+// index of one product, and no per-tensor sketch is ever written or summed.
+static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
+                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
+                          const double *const *X, const double *const *DL, const double *const *DR, double *out,
+                          int64_t out_stride, int accumulate, int stream, bool sum)
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(nb >= 1, "ttsk_tt_sketch_batch: need nb >= 1, got %d", nb);
@@ -201,17 +226,19 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
                  "ttsk_tt_sketch: right rank slice %d out of range", mu);
     }
     const int64_t one = ttsk_tt_sketch_size(d, n, l_lo, l_hi, r_lo, r_hi);
-    TTSK_ARG(nb == 1 || out_stride >= one, "ttsk_tt_sketch_batch: out_stride %lld < sketch size %lld",
+    TTSK_ARG(sum || nb == 1 || out_stride >= one, "ttsk_tt_sketch_batch: out_stride %lld < sketch size %lld",
              (long long)out_stride, (long long)one);
     if (nb > SK_MAXB) {   // larger batches in slices of SK_MAXB tensors
         for (int b0 = 0; b0 < nb; b0 += SK_MAXB) {
             const int cnt = nb - b0 < SK_MAXB ? nb - b0 : SK_MAXB;
-            int rc = ttsk_tt_sketch_batch(cnt, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X + (size_t)b0 * d, DL, DR,
-                                          out + (size_t)b0 * out_stride, out_stride, accumulate, stream);
+            int rc = tt_sketch_core(cnt, d, n, s, lt, l_lo, l_hi, rt, r_lo, r_hi, X + (size_t)b0 * d, DL, DR,
+                                    sum ? out : out + (size_t)b0 * out_stride, out_stride, (sum && b0) ? 1 : accumulate,
+                                    stream, sum);
             if (rc) return rc;
         }
         return TTSK_OK;
     }
+    if (nb == 1) sum = false;
     // The right chain runs on the caller's stream, the left chain on a helper stream (the two are
     // independent until Psi / Omega need both); the Psi products are then dealt over both.  The
     // helper is forked from / joined into `stream`, so callers (and hipGraph capture) see one stream.
@@ -220,25 +247,39 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
     const char *single = getenv("TTSK_SINGLE_STREAM");
     const int aux = (single && single[0] == '1') ? stream : (stream + 1) % TTSK_NUM_STREAMS;
     TTSK_STREAM(st_aux, aux);
-    // workspace of one tensor (slot DRIVER of `stream`, tensor b at ws + b * tot):
-    // Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]), one T buffer per left mode (kept for
-    // the Psi phase) and one T buffer for the right chain
+    // Workspace (slot DRIVER of `stream`), one block per QUANTITY with the nb tensors behind one another:
+    // Lc[mu] (s[mu+1] x lt[mu+1]), Rc[j] (s[d-1-j] x rt[j+1]), T[mu] per left mode (kept for the Psi phase), one
+    // T buffer for the right chain.  Tensor b of a quantity of size sz sits at block + b * stride(sz), stride =
+    // sz rounded up to even (16-byte operand loads).  Where sz is even the nb chain matrices of a mode are ONE
+    // (nb s) x rank matrix: the two-launch chain step and the Psi / Omega of a sum then run as one product over
+    // all tensors ("merged" below) and read the DRM core once instead of once per tensor.
+    auto even = [](size_t v) { return v + (v & 1); };
+    auto blk = [](size_t v) { return (v + 31) & ~(size_t)31; };
     size_t tot = 0;
-    std::vector<size_t> offL(d - 1), offR(d - 1), offT(d);
-    for (int mu = 0; mu < d - 1; ++mu) { offL[mu] = tot; tot += (size_t)s[mu + 1] * lt[mu + 1]; }
-    for (int j = 0; j < d - 1; ++j) { offR[j] = tot; tot += (size_t)s[d - 1 - j] * rt[j + 1]; }
-    for (int mu = 1; mu < d; ++mu) { offT[mu] = tot; tot += (size_t)lt[mu] * n[mu] * s[mu + 1]; }
+    std::vector<size_t> offL(d - 1), offR(d - 1), offT(d), szL(d - 1), szR(d - 1), szT(d);
+    for (int mu = 0; mu < d - 1; ++mu) { szL[mu] = even((size_t)s[mu + 1] * lt[mu + 1]); offL[mu] = tot; tot += blk(nb * szL[mu]); }
+    for (int j = 0; j < d - 1; ++j) { szR[j] = even((size_t)s[d - 1 - j] * rt[j + 1]); offR[j] = tot; tot += blk(nb * szR[j]); }
+    for (int mu = 1; mu < d; ++mu) { szT[mu] = even((size_t)lt[mu] * n[mu] * s[mu + 1]); offT[mu] = tot; tot += blk(nb * szT[mu]); }
     size_t tr_max = 0;
     for (int mu = 1; mu < d - 1; ++mu) {
         size_t tr = (size_t)rt[d - 1 - mu] * n[mu] * s[mu];
         tr_max = tr > tr_max ? tr : tr_max;
     }
-    const size_t offTR = tot;
-    tot += tr_max;
-    tot = (tot + 31) & ~(size_t)31;   // 256-byte aligned per-tensor blocks (16-byte operand loads)
-    double *ws0 = (double *)scratch(stream, SCRATCH_DRIVER, (size_t)nb * tot * 8);
+    const size_t szTR = even(tr_max), offTR = tot;
+    tot += blk(nb * szTR);
+    const size_t szP0 = even((size_t)n[0] * (r_hi[d - 2] - r_lo[d - 2])), offP0 = tot;   // sum mode: Psi_0 per tensor
+    if (sum) tot += blk(nb * szP0);
+    double *ws0 = (double *)scratch(stream, SCRATCH_DRIVER, tot * 8);
     if (!ws0) return TTSK_ERR_HIP;
-    auto ws = [&](int b) { return ws0 + (size_t)b * tot; };
+    auto Lp = [&](int b, int mu) { return ws0 + offL[mu] + (size_t)b * szL[mu]; };
+    auto Rp = [&](int b, int j) { return ws0 + offR[j] + (size_t)b * szR[j]; };
+    auto Tp0 = [&](int b, int mu) { return ws0 + offT[mu] + (size_t)b * szT[mu]; };     // per-tensor T[q][k][p']
+    auto TRp = [&](int b) { return ws0 + offTR + (size_t)b * szTR; };
+    // "merged" needs the tensors of a chain matrix exactly behind one another
+    auto packedL = [&](int mu) { return szL[mu] == (size_t)s[mu + 1] * lt[mu + 1]; };
+    auto packedR = [&](int j) { return szR[j] == (size_t)s[d - 1 - j] * rt[j + 1]; };
+    static const int merge_on = [] { const char *e = getenv("TTSK_TT_MERGE"); return e ? atoi(e) : 1; }();
+    std::vector<int> t_inter(d, 0);     // T[mu] stored interleaved: T[(q,k)][(b,p')], row length nb * s[mu+1]
     auto Xc = [&](int b, int mu) { return X[(size_t)b * d + mu]; };
     auto outb = [&](int b) { return out + (size_t)b * out_stride; };
     int rc;
@@ -253,7 +294,7 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
         BatchPtrs p{};
         if (j == 0) {
             // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
-            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, mu); p.B[b] = DR[j]; p.C[b] = ws(b) + offR[j]; }
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, mu); p.B[b] = DR[j]; p.C[b] = Rp(b, j); }
             CK(gemm_batch(5, nb, desc2(sn, rhop, 1, nn, nn * sp, 0, sp, 0, rhop, 1, rhop, 1, 0), p, stream, st));
             continue;
         }
@@ -261,7 +302,7 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
         {
             const double *Wp[SK_MAXB], *Xp[SK_MAXB];
             double *Op[SK_MAXB];
-            for (int b = 0; b < nb; ++b) { Wp[b] = ws(b) + offR[j - 1]; Xp[b] = Xc(b, mu); Op[b] = ws(b) + offR[j]; }
+            for (int b = 0; b < nb; ++b) { Wp[b] = Rp(b, j - 1); Xp[b] = Xc(b, mu); Op[b] = Rp(b, j); }
             ChainStepArgs cs{nb, (int)nn, (int)sp, (int)rho, (int)rhop, (int)sn, Wp, rho, Xp, nn * sp, sp, 1, sn * nn * sp,
                              DR[j], nullptr, Op};
             g_cls = 1;
@@ -270,19 +311,29 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             if (fz < 0) return fz;
             if (fz == 1) continue;
         }
-        // otherwise: T[q, k, p''] = sum_p Rc[p,q] X[p'',k,p] (a product batched over k whose batch index
-        // joins the streamed index), so that both operands of GEMM2 are contiguous along their output index
-        for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offR[j - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offTR; }
+        // otherwise two launches.  T[q, k, b, p''] = sum_p Rc_b[p,q] X_b[p'',k,p]: a product batched over k whose
+        // batch index joins the streamed index, written interleaved over the tensors (row (q,k), columns (b,p'')) ...
+        const bool merged = merge_on && nb > 1 && packedR(j) && (int64_t)nb * sn * rho * nn <= (int64_t)nb * szTR;
+        const int64_t ldt = merged ? (int64_t)nb * sn : sn;
+        for (int b = 0; b < nb; ++b) { p.A[b] = Rp(b, j - 1); p.B[b] = Xc(b, mu); p.C[b] = merged ? TRp(0) + (size_t)b * sn : TRp(b); }
         ttsk_gemm_desc g1{};
         g1.batch = nn; g1.M = rho; g1.N = sn; g1.Ko = 1; g1.Ki = sp;
         g1.a_b = 0; g1.a_m = 1; g1.a_ki = rho;
         g1.b_b = sp; g1.b_ki = 1; g1.b_n = nn * sp;
-        g1.c_b = sn; g1.c_m = nn * sn; g1.c_n = 1;
+        g1.c_b = ldt; g1.c_m = nn * ldt; g1.c_n = 1;
         g1.alpha = 1.0;
-        const int fast = gemm_batch(0, nb, g1, p, stream, st, true);
+        const int fast = gemm_batch(0, nb, g1, p, stream, st, !merged);
         if (fast < 0) return fast;
         BatchPtrs q{};
-        for (int b = 0; b < nb; ++b) { q.A[b] = ws(b) + offTR; q.B[b] = DR[j]; q.C[b] = ws(b) + offR[j]; }
+        if (merged) {
+            // ... so that Rn_all[(b,p''), q'] = sum_{q,k} T[(q,k), (b,p'')] E[q,k,q'] is ONE long product: E is read
+            // once, not once per tensor
+            q.A[0] = TRp(0); q.B[0] = DR[j]; q.C[0] = Rp(0, j);
+            CK(gemm_batch(1, 1, desc2((int64_t)nb * sn, rhop, rho, nn, 1, nn * ldt, ldt, nn * rhop, rhop, 1, rhop, 1, 0), q,
+                          stream, st));
+            continue;
+        }
+        for (int b = 0; b < nb; ++b) { q.A[b] = TRp(b); q.B[b] = DR[j]; q.C[b] = Rp(b, j); }
         if (fast == 1) {
             // Rn[p'', q'] = sum_{q,k} T[q,k,p''] E[q,k,q']
             CK(gemm_batch(1, nb, desc2(sn, rhop, rho, nn, 1, nn * sn, sn, nn * rhop, rhop, 1, rhop, 1, 0), q, stream, st));
@@ -299,7 +350,7 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
         BatchPtrs p{};
         if (mu == 0) {
             // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
-            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = DL[0]; p.C[b] = ws(b) + offL[0]; }
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = DL[0]; p.C[b] = Lp(b, 0); }
             CK(gemm_batch(5, nb, desc2(sp, lt[1], 1, nn, 1, 0, sp, 0, lt[1], 1, lt[1], 1, 0), p, aux, st_aux));
             continue;
         }
@@ -308,9 +359,7 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             // first choice: T and L_mu from one launch (chain_fused.h); T is still stored, Psi_mu needs it
             const double *Wp[SK_MAXB], *Xp[SK_MAXB];
             double *Op[SK_MAXB], *Tp[SK_MAXB];
-            for (int b = 0; b < nb; ++b) {
-                Wp[b] = ws(b) + offL[mu - 1]; Xp[b] = Xc(b, mu); Op[b] = ws(b) + offL[mu]; Tp[b] = ws(b) + offT[mu];
-            }
+            for (int b = 0; b < nb; ++b) { Wp[b] = Lp(b, mu - 1); Xp[b] = Xc(b, mu); Op[b] = Lp(b, mu); Tp[b] = Tp0(b, mu); }
             ChainStepArgs cs{nb, (int)nn, (int)sn, (int)lfull, (int)lt[mu + 1], (int)sp, Wp, lfull, Xp, 1, sp, nn * sp,
                              sn * nn * sp, DL[mu], Tp, Op};
             g_cls = 3;
@@ -319,14 +368,35 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
             if (fz < 0) return fz;
             if (fz == 1) continue;
         }
+        const bool merged = merge_on && nb > 1 && mu < d - 1 && packedL(mu);
+        if (merged) {
+            // T[q, k, b, p'] = sum_p Lc_b[p,q] X_b[p,k,p'] interleaved over the tensors (batched over k) ...
+            t_inter[mu] = 1;
+            const int64_t ldt = (int64_t)nb * sp;
+            double *T0 = ws0 + offT[mu];
+            for (int b = 0; b < nb; ++b) { p.A[b] = Lp(b, mu - 1); p.B[b] = Xc(b, mu); p.C[b] = T0 + (size_t)b * sp; }
+            ttsk_gemm_desc g1{};
+            g1.batch = nn; g1.M = lfull; g1.N = sp; g1.Ko = 1; g1.Ki = sn;
+            g1.a_b = 0; g1.a_m = 1; g1.a_ki = lfull;
+            g1.b_b = sp; g1.b_ki = nn * sp; g1.b_n = 1;
+            g1.c_b = ldt; g1.c_m = nn * ldt; g1.c_n = 1;
+            g1.alpha = 1.0;
+            CK(gemm_batch(2, nb, g1, p, aux, st_aux));
+            // ... and L_all[(b,p'), q'] = sum_{q,k} T[(q,k), (b,p')] D[q,k,q'] as one long product
+            BatchPtrs q{};
+            q.A[0] = T0; q.B[0] = DL[mu]; q.C[0] = Lp(0, mu);
+            CK(gemm_batch(3, 1, desc2((int64_t)nb * sp, lt[mu + 1], lfull, nn, 1, nn * ldt, ldt, nn * lt[mu + 1], lt[mu + 1], 1,
+                                      lt[mu + 1], 1, 0), q, aux, st_aux));
+            continue;
+        }
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
-        for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offL[mu - 1]; p.B[b] = Xc(b, mu); p.C[b] = ws(b) + offT[mu]; }
+        for (int b = 0; b < nb; ++b) { p.A[b] = Lp(b, mu - 1); p.B[b] = Xc(b, mu); p.C[b] = Tp0(b, mu); }
         CK(gemm_batch(mu == d - 1 ? 5 : 2, nb, desc2(lfull, nn * sp, 1, sn, 1, 0, lfull, 0, nn * sp, 1, nn * sp, 1, 0), p,
                       aux, st_aux));
         if (mu < d - 1) {
             // L_mu[p',q'] = sum_{q,k} T[q,k,p'] D[q,k,q']
             BatchPtrs q{};
-            for (int b = 0; b < nb; ++b) { q.A[b] = ws(b) + offT[mu]; q.B[b] = DL[mu]; q.C[b] = ws(b) + offL[mu]; }
+            for (int b = 0; b < nb; ++b) { q.A[b] = Tp0(b, mu); q.B[b] = DL[mu]; q.C[b] = Lp(b, mu); }
             CK(gemm_batch(3, nb, desc2(sp, lt[mu + 1], 1, lfull * nn, 1, 0, sp, 0, lt[mu + 1], 1, lt[mu + 1], 1, 0), q,
                           aux, st_aux));
         }
@@ -356,46 +426,79 @@ int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, cons
         hipStream_t stq = stream_of(q);
         // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
         const int jr = d - 2 - mu;
-        const size_t offRm = mu < d - 1 ? offR[jr] + r_lo[jr] : 0;
         const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
+        auto Rm = [&](int b) { return Rp(b, jr) + r_lo[jr]; };
         BatchPtrs p{};
-        if (mu == 0) {
+        if (mu == 0 && sum) {
+            // the cores X_b,0 are anywhere in memory: per-tensor products into the workspace, then one sum
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = Rm(b); p.C[b] = ws0 + offP0 + (size_t)b * szP0; }
+            CK(gemm_batch(5, nb, desc2(nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, 0), p, q, stq));
+            CK(ttsk_sum_slices(out + psi_at[0], ws0 + offP0, nb, szP0, (size_t)(nn * r), accumulate, q));
+        } else if (mu == 0) {
             // Psi_0[0,k,c] = sum_{p'} X_0[0,k,p'] R_0[p',c]
-            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = ws(b) + offRm; p.C[b] = outb(b) + psi_at[0]; }
+            for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = Rm(b); p.C[b] = outb(b) + psi_at[0]; }
             CK(gemm_batch(5, nb, desc2(nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
         } else {
             const int64_t l = l_hi[mu - 1] - l_lo[mu - 1];
-            const size_t offTs = offT[mu] + l_lo[mu - 1] * nn * sp;   // rows of the rank slice
-            if (mu < d - 1) {
+            // T_b[(q,k), p'] for the rows of the rank slice: tensor b, row stride
+            const int64_t ldt = t_inter[mu] ? (int64_t)nb * sp : sp;
+            auto Tm = [&](int b) {
+                return t_inter[mu] ? ws0 + offT[mu] + (size_t)(l_lo[mu - 1] * nn) * ldt + (size_t)b * sp
+                                   : Tp0(b, mu) + (size_t)(l_lo[mu - 1] * nn) * sp;
+            };
+            if (mu < d - 1 && sum) {
+                // Psi[(q,k), c] = sum_{b, p'} T_b[(q,k), p'] R_b[p', c]: (b, p') is one contracted index when both
+                // operands hold the tensors behind one another, a two-level one otherwise
+                if (t_inter[mu] && packedR(jr))
+                    rc = gemm(4, l * nn, r, 1, (int64_t)nb * sp, Tm(0), ldt, 0, 1, Rm(0), 0, ldr, 1, out + psi_at[mu], r, 1,
+                              accumulate, q);
+                else
+                    rc = gemm(4, l * nn, r, nb, sp, Tm(0), ldt, t_inter[mu] ? sp : (int64_t)szT[mu], 1, Rm(0), (int64_t)szR[jr],
+                              ldr, 1, out + psi_at[mu], r, 1, accumulate, q);
+                if (rc) return rc;
+            } else if (mu < d - 1) {
                 // Psi[q,k,c] = sum_{p'} T[q,k,p'] R[p',c]   (M=(q,k), N=c, K=p')
-                for (int b = 0; b < nb; ++b) { p.A[b] = ws(b) + offTs; p.B[b] = ws(b) + offRm; p.C[b] = outb(b) + psi_at[mu]; }
+                for (int b = 0; b < nb; ++b) { p.A[b] = Tm(b); p.B[b] = Rm(b); p.C[b] = outb(b) + psi_at[mu]; }
                 {
-                    StreamSmallArgs ss{nb, (int)(l * nn), (int)sp, (int)r, p.A, sp, p.B, ldr, p.C, r, accumulate};
+                    StreamSmallArgs ss{nb, (int)(l * nn), (int)sp, (int)r, p.A, ldt, p.B, ldr, p.C, r, accumulate};
                     g_cls = 4;
                     const int fz = (l * nn < (1ll << 30)) ? stream_small_try(ss, q, stq) : 0;
                     g_cls = NCLS - 1;
                     if (fz < 0) return fz;
                     if (fz == 1) goto psi_done;
                 }
-                CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
+                CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, ldt, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
             psi_done:;
+            } else if (sum) {
+                // last mode: Psi_{d-1}[q,k,0] = sum_b T_b[q,k,0]
+                CK(ttsk_sum_slices(out + psi_at[mu], Tm(0), nb, szT[mu], (size_t)(l * nn), accumulate, q));
             } else {
                 // last mode: Psi_{d-1}[q,k,0] = T[q,k,0]
                 for (int b = 0; b < nb; ++b) {
-                    if (accumulate) CK(ttsk_axpby(outb(b) + psi_at[mu], ws(b) + offTs, 1.0, 1.0, (size_t)(l * nn), q));
-                    else TTSK_HIP(hipMemcpyAsync(outb(b) + psi_at[mu], ws(b) + offTs, (size_t)(l * nn) * 8,
-                                                 hipMemcpyDeviceToDevice, stq));
+                    if (accumulate) CK(ttsk_axpby(outb(b) + psi_at[mu], Tm(b), 1.0, 1.0, (size_t)(l * nn), q));
+                    else TTSK_HIP(hipMemcpyAsync(outb(b) + psi_at[mu], Tm(b), (size_t)(l * nn) * 8, hipMemcpyDeviceToDevice, stq));
                 }
             }
         }
         if (mu < d - 1) {
+            const int64_t l = l_hi[mu] - l_lo[mu];
+            if (sum) {
+                // Omega[q, c] = sum_{b, p} L_b[p, q] R_b[p, c]
+                if (packedL(mu) && packedR(jr))
+                    rc = gemm(5, l, r, 1, (int64_t)nb * sp, Lp(0, mu) + l_lo[mu], 1, 0, lt[mu + 1], Rm(0), 0, ldr, 1,
+                              out + om_at[mu], r, 1, accumulate, q);
+                else
+                    rc = gemm(5, l, r, nb, sp, Lp(0, mu) + l_lo[mu], 1, (int64_t)szL[mu], lt[mu + 1], Rm(0), (int64_t)szR[jr], ldr,
+                              1, out + om_at[mu], r, 1, accumulate, q);
+                if (rc) return rc;
+                continue;
+            }
             // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]; the workspace blocks and the outputs of a
             // batch are equally spaced, so the nb products are one batched launch
-            const int64_t l = l_hi[mu] - l_lo[mu];
             ttsk_gemm_desc od = desc2(l, r, 1, sp, 1, 0, lt[mu + 1], 0, ldr, 1, r, 1, accumulate);
-            od.batch = nb; od.a_b = (int64_t)tot; od.b_b = (int64_t)tot; od.c_b = out_stride;
+            od.batch = nb; od.a_b = (int64_t)szL[mu]; od.b_b = (int64_t)szR[jr]; od.c_b = out_stride;
             g_cls = 5;
-            rc = ttsk_gemm(&od, ws(0) + offL[mu] + l_lo[mu], ws(0) + offRm, outb(0) + om_at[mu], nullptr, q);
+            rc = ttsk_gemm(&od, Lp(0, mu) + l_lo[mu], Rm(0), outb(0) + om_at[mu], nullptr, q);
             g_cls = NCLS - 1;
             if (rc) return rc;
         }

@@ -19,7 +19,7 @@ from .drm.tensor_train_drm import TensorTrainDRM
 from .tensor import TensorSum, TensorTrain
 
 _I64 = ctypes.c_int64
-MAX_BATCH = 32   # tensors per batched pass (SK_MAXB in csrc/skinny.h)
+MAX_BATCH = 32   # tensors per batched pass (SK_MAXB in csrc/skinny.h); the library slices larger batches itself
 
 
 class TTSketchPlan:
@@ -76,6 +76,13 @@ class TTSketchPlan:
                  self.r_lo, self.r_hi, X_ptrs, self.DL, self.DR, ctypes.c_void_p(out.ptr),
                  _I64(out_stride), 1 if accumulate else 0, stream)
 
+    def run_sum(self, X_ptrs, nb: int, out: DevArray, accumulate: bool = False, stream: int = 0):
+        """The sketch of the SUM of ``nb`` tensors of the plan's signature as one packed sketch at ``out``
+        (``ttsk_tt_sketch_sum``: chains per tensor, Psi / Omega contracted over (tensor, rank) at once)."""
+        nat.call("ttsk_tt_sketch_sum", nb, self.d, self.n, self.s, self.lt, self.l_lo, self.l_hi, self.rt,
+                 self.r_lo, self.r_hi, X_ptrs, self.DL, self.DR, ctypes.c_void_p(out.ptr),
+                 1 if accumulate else 0, stream)
+
     def views(self, out: DevArray) -> Tuple[List[DevArray], List[DevArray]]:
         """Psi / Omega arrays as views into the packed buffer."""
         d, off = self.d, 0
@@ -111,37 +118,23 @@ def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[lis
         return None
     if tuple(left_drm.shape) != tuple(tensor.shape) or tuple(right_drm.shape) != tuple(tensor.shape):
         raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensor.shape}")
-    # Terms of one signature (mode sizes, TT ranks) go through the device in batches: every chain
-    # product is then one launch over the whole batch (ttsk_tt_sketch_batch) and the partial
-    # sketches are summed afterwards -- the TensorSum loop of sketch_dispatch.py:85-139.
-    from .device import axpby
+    # Terms of one signature (mode sizes, TT ranks) go through the device together: every chain product is one
+    # launch over all of them and Psi / Omega come out already summed (ttsk_tt_sketch_sum) -- the TensorSum loop
+    # of sketch_dispatch.py:85-139 without its per-term sketches.
     groups = {}
     for tt in terms:
         groups.setdefault((tuple(tt.shape), tuple(tt.rank)), []).append(tt)
-    out, plan0 = None, None
+    out, plan0, first = None, None, True
     for (shape, rank), tts in groups.items():
         plan = TTSketchPlan(shape, rank, left_drm, right_drm)
         plan0 = plan0 or plan
         if out is None:
-            out = DevArray.zeros((plan.size,))
-        for b0 in range(0, len(tts), MAX_BATCH):
-            chunk = tts[b0:b0 + MAX_BATCH]
-            if len(chunk) == 1:
-                ptrs, keep = plan.core_pointers(chunk[0])
-                plan.run(ptrs, out, accumulate=True)
-                continue
-            keep, flat = [], []
-            for tt in chunk:
-                ptrs, k = plan.core_pointers(tt)
-                keep.append(k)
-                flat += [ptrs[i] for i in range(plan.d)]
-            stride = plan.size + (plan.size & 1)
-            tmp = DevArray.empty((len(chunk) * stride,))
-            plan.run_batch((ctypes.c_void_p * len(flat))(*flat), len(chunk), tmp, stride)
-            if plan.size % 2 == 0:
-                nat.call("ttsk_sum_slices", ctypes.c_void_p(out.ptr), ctypes.c_void_p(tmp.ptr), len(chunk),
-                         ctypes.c_size_t(stride), ctypes.c_size_t(plan.size), 1, 0)
-            else:
-                for b in range(len(chunk)):
-                    axpby(out, tmp[b * stride:b * stride + plan.size], 1.0, 1.0)
+            out = DevArray.empty((plan.size,))
+        keep, flat = [], []
+        for tt in tts:
+            ptrs, k = plan.core_pointers(tt)
+            keep.append(k)
+            flat += [ptrs[i] for i in range(plan.d)]
+        plan.run_sum((ctypes.c_void_p * len(flat))(*flat), len(tts), out, accumulate=not first)
+        first = False
     return plan0.views(out)
