@@ -452,11 +452,11 @@ def bench_c5(args, job):
                 dtype="f64", data="synthetic",
                 config=dict(workload="C5: stream_sketch of a TensorSum of 32 rank-20 TTs, d=6 n=128, shared TensorTrainDRMs l=50 r=100; "
                                      "terms dealt over the ranks, one all-reduce (stream_sketch_sharded)" , terms=terms),
-                roofline=dict(bound="mfma", kernel="ttsk_tt_sketch_batch pass of the 32 terms (fused chain steps + Psi)",
+                roofline=dict(bound="mfma", kernel="ttsk_tt_sketch_sum of the 32 terms (two-launch chain steps merged over the terms, Psi / Omega over (term, rank))",
                               achieved=gf / t_step * 1e-12, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s",
                               frac=gf / t_step * 1e-12 / PEAK_F64_MFMA_TF, traffic=None,
                               what="algorithmic flops of the 32 term sketches (SURVEY 8d: 0.443 GF each) / wall time of one "
-                                   "stream_sketch call incl. Python and the term sum"),
+                                   "stream_sketch call incl. Python"),
                 cpu_baseline=cpu)
 
 

@@ -607,6 +607,55 @@ def test_batched_one_call_path(tsa):
                 assert rel(a.get(), c) < TOL
 
 
+def test_sketch_of_a_sum_in_one_call(tsa):
+    """ttsk_tt_sketch_sum: the sketch of a sum of nb TTs of one signature == the sum of the oracle's sketches
+    (sketch_dispatch.py:85-139), for odd and even sizes (merged and two-level contracted index), rank slices,
+    nb > 32 (sliced by the library), accumulate, and shapes large enough for the chain kernels (the interleaved
+    intermediate of the two-launch step) with and without the fused step kernel's cover."""
+    import ctypes
+    from tt_sketch_amd import tt_fused
+    from tt_sketch_amd.device import DevArray
+    from tests.gpu_build import make_drm, make_tensor
+    rng = np.random.default_rng(29)
+    for shape, ranks, lr, rr, nb in [((9, 12, 7, 10, 8), (3, 6, 5, 4), (4, 7, 6, 5), (6, 9, 8, 7), 3),
+                                     ((8, 6, 10, 4), (2, 4, 6), (4, 6, 2), (6, 8, 4), 5),
+                                     ((5, 4, 6), (3, 2), (2, 3), (4, 3), 35),
+                                     ((150, 160, 150, 140), (30, 32, 28), (26, 24, 22), (28, 30, 34), 3),
+                                     ((150, 151, 149), (31, 29), (25, 27), (33, 35), 2),
+                                     ((128, 128, 128, 128), (20, 20, 20), (50, 50, 50), (100, 100, 100), 6),
+                                     ((64, 64, 64, 64), (100, 100, 100), (50, 50, 50), (100, 100, 100), 4)]:
+        ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
+        if len(shape) == 5:
+            ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)
+            rd.rank_min, rd.rank_max = (0, 3, 1, 2), (5, 8, 9, 6)       # walking order of the right DRM
+        L, R = make_drm(ld), make_drm(rd)
+        tts = [orc.random_tt(shape, ranks, rng) for _ in range(nb)]
+        dev = [make_tensor("tt", c) for c in tts]
+        plan = tt_fused.TTSketchPlan(dev[0].shape, dev[0].rank, L, R)
+        keep, flat = [], []
+        for t in dev:
+            ptrs, k = plan.core_pointers(t)
+            keep.append(k)
+            flat += [ptrs[i] for i in range(plan.d)]
+        X = (ctypes.c_void_p * len(flat))(*flat)
+        want = None
+        for cores in tts:
+            oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
+            want = [a + b for a, b in zip(want, oP + oO)] if want else list(oP + oO)
+        out = DevArray.empty((plan.size,))
+        plan.run_sum(X, nb, out)
+        Psi, Om = plan.views(out)
+        for a, c in zip(Psi + Om, want):
+            assert a.shape == c.shape and rel(a.get(), c) < 1e-12, (shape, nb, rel(a.get(), c))
+        plan.run_sum(X, nb, out, accumulate=True)              # out += the same sketch
+        for a, c in zip(Psi + Om, want):
+            assert rel(a.get(), 2 * c) < 1e-12, (shape, nb, "accumulate")
+        # ... and through the public API
+        sk = tsa.general_sketch(tsa.TensorSum(dev), L, R, tsa.SketchMethod.streaming)
+        for a, c in zip(sk.Psi_cores + sk.Omega_mats, want):
+            assert rel(np.asarray(a), c) < 1e-12
+
+
 def test_round_on_device(tsa):
     """TensorTrain.round_dev / orthogonalize_dev == the host versions (reference tensor.py:446-484,
     :559-572) as tensors; orthogonality and rank rules identical; ttsk_svd_small reconstructs."""
