@@ -724,8 +724,9 @@ __global__ __launch_bounds__(512) void skinny_r_kernel(SkinnyR a)
 
 // sum of the per-chunk partial results of the long-K kernel and of the fused chain step (skinny.hip)
 struct ReduceOut { double *C[SK_MAXB]; };
-__global__ void skinny_r_reduce(const double *__restrict__ slab_all, int chunks, int M, int N, int m_tiles, int64_t Mtot,
-                                ReduceOut outs, int64_t c_m, int64_t c_n, double alpha, int accumulate);
+// out[m, n] (+)= alpha sum_c slab[c][m][n] for nprob x m_tiles (problem, row tile) blocks of slabs behind one another
+int launch_r_reduce(hipStream_t st, const double *slab, int chunks, int M, int N, int m_tiles, int64_t Mtot, const ReduceOut &ro,
+                    int nprob, int64_t c_m, int64_t c_n, double alpha, int accumulate);
 
 // 1 = launched, 0 = shape not covered (caller falls through to the generic kernel), < 0 = error
 int skinny_try(const ttsk_gemm_desc &d, const double *A, const double *B, double *C, const double *k_scale,

@@ -284,11 +284,9 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     auto outb = [&](int b) { return out + (size_t)b * out_stride; };
     int rc;
 #define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
-    CK(ttsk_stream_wait(aux, stream));   // fork
-
-    // ---- right chain (stream): walks modes d-1, ..., 1 on the transposed tensor (views only).
-    // Xt_j[p,k,p''] = X_mu[p'',k,p], mu = d-1-j.
-    for (int j = 0; j < d - 1; ++j) {
+    // ---- the pieces: one step of either chain, and the Psi / Omega of one mode on a given stream
+    // right chain: walks modes d-1, ..., 1 on the transposed tensor (views only).  Xt_j[p,k,p''] = X_mu[p'',k,p], mu = d-1-j.
+    auto right_step = [&](int j) -> int {
         const int mu = d - 1 - j;
         const int64_t sp = s[mu + 1], sn = s[mu], nn = n[mu], rho = rt[j], rhop = rt[j + 1];
         BatchPtrs p{};
@@ -296,7 +294,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             // Rc_0[p'',q'] = sum_k X[p'',k,0] E[0,k,q']
             for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, mu); p.B[b] = DR[j]; p.C[b] = Rp(b, j); }
             CK(gemm_batch(5, nb, desc2(sn, rhop, 1, nn, nn * sp, 0, sp, 0, rhop, 1, rhop, 1, 0), p, stream, st));
-            continue;
+            return TTSK_OK;
         }
         // first choice: both products in one launch, T never written (chain_fused.h)
         {
@@ -309,7 +307,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             const int fz = (sp <= 128 && sn <= 128 && rho <= 128 && rhop <= 128) ? chain_fused_try(cs, stream, st) : 0;
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
-            if (fz == 1) continue;
+            if (fz == 1) return TTSK_OK;
         }
         // otherwise two launches.  T[q, k, b, p''] = sum_p Rc_b[p,q] X_b[p'',k,p]: a product batched over k whose
         // batch index joins the streamed index, written interleaved over the tensors (row (q,k), columns (b,p'')) ...
@@ -331,7 +329,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             q.A[0] = TRp(0); q.B[0] = DR[j]; q.C[0] = Rp(0, j);
             CK(gemm_batch(1, 1, desc2((int64_t)nb * sn, rhop, rho, nn, 1, nn * ldt, ldt, nn * rhop, rhop, 1, rhop, 1, 0), q,
                           stream, st));
-            continue;
+            return TTSK_OK;
         }
         for (int b = 0; b < nb; ++b) { q.A[b] = TRp(b); q.B[b] = DR[j]; q.C[b] = Rp(b, j); }
         if (fast == 1) {
@@ -343,16 +341,17 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             // Rn[p'', q'] = sum_{q,k} T[q,p'',k] E[q,k,q']
             CK(gemm_batch(1, nb, desc2(sn, rhop, rho, nn, nn, sn * nn, 1, nn * rhop, rhop, 1, rhop, 1, 0), q, stream, st));
         }
-    }
-    // ---- left chain (aux): L_mu and the shared products T_mu = L_{mu-1}^T X_mu
-    for (int mu = 0; mu < d; ++mu) {
+        return TTSK_OK;
+    };
+    // left chain: L_mu and the shared products T_mu = L_{mu-1}^T X_mu
+    auto left_step = [&](int mu) -> int {
         const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
         BatchPtrs p{};
         if (mu == 0) {
             // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
             for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = DL[0]; p.C[b] = Lp(b, 0); }
             CK(gemm_batch(5, nb, desc2(sp, lt[1], 1, nn, 1, 0, sp, 0, lt[1], 1, lt[1], 1, 0), p, aux, st_aux));
-            continue;
+            return TTSK_OK;
         }
         const int64_t lfull = lt[mu];
         if (mu < d - 1) {
@@ -366,7 +365,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             const int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
-            if (fz == 1) continue;
+            if (fz == 1) return TTSK_OK;
         }
         const bool merged = merge_on && nb > 1 && mu < d - 1 && packedL(mu);
         if (merged) {
@@ -387,7 +386,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             q.A[0] = T0; q.B[0] = DL[mu]; q.C[0] = Lp(0, mu);
             CK(gemm_batch(3, 1, desc2((int64_t)nb * sp, lt[mu + 1], lfull, nn, 1, nn * ldt, ldt, nn * lt[mu + 1], lt[mu + 1], 1,
                                       lt[mu + 1], 1, 0), q, aux, st_aux));
-            continue;
+            return TTSK_OK;
         }
         // T[q,k,p'] = sum_p Lc[p,q] X[p,k,p']      (M=q (all lfull columns), N=(k,p'), K=p)
         for (int b = 0; b < nb; ++b) { p.A[b] = Lp(b, mu - 1); p.B[b] = Xc(b, mu); p.C[b] = Tp0(b, mu); }
@@ -400,12 +399,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             CK(gemm_batch(3, nb, desc2(sp, lt[mu + 1], 1, lfull * nn, 1, 0, sp, 0, lt[mu + 1], 1, lt[mu + 1], 1, 0), q,
                           aux, st_aux));
         }
-    }
-    // both chains are needed from here on, on both streams
-    CK(ttsk_stream_wait(stream, aux));
-    CK(ttsk_stream_wait(aux, stream));
-
-    // ---- Psi and Omega, dealt over the two streams
+        return TTSK_OK;
+    };
     std::vector<size_t> psi_at(d), om_at(d - 1);
     {
         size_t p = 0;
@@ -420,9 +415,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
         }
     }
-    for (int mu = 0; mu < d; ++mu) {
+    auto psi_omega = [&](int mu, int q) -> int {
         const int64_t sp = s[mu + 1], nn = n[mu];
-        const int q = (mu & 1) ? aux : stream;
         hipStream_t stq = stream_of(q);
         // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
         const int jr = d - 2 - mu;
@@ -465,10 +459,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                     const int fz = (l * nn < (1ll << 30)) ? stream_small_try(ss, q, stq) : 0;
                     g_cls = NCLS - 1;
                     if (fz < 0) return fz;
-                    if (fz == 1) goto psi_done;
+                    if (fz == 0) CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, ldt, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
                 }
-                CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, ldt, 0, 1, 0, ldr, 1, r, 1, accumulate), p, q, stq));
-            psi_done:;
             } else if (sum) {
                 // last mode: Psi_{d-1}[q,k,0] = sum_b T_b[q,k,0]
                 CK(ttsk_sum_slices(out + psi_at[mu], Tm(0), nb, szT[mu], (size_t)(l * nn), accumulate, q));
@@ -491,7 +483,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                     rc = gemm(5, l, r, nb, sp, Lp(0, mu) + l_lo[mu], 1, (int64_t)szL[mu], lt[mu + 1], Rm(0), (int64_t)szR[jr], ldr,
                               1, out + om_at[mu], r, 1, accumulate, q);
                 if (rc) return rc;
-                continue;
+                return TTSK_OK;
             }
             // Omega_mu = L_mu[:, lo:hi]^T R_mu[:, lo:hi]; the workspace blocks and the outputs of a
             // batch are equally spaced, so the nb products are one batched launch
@@ -502,10 +494,26 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             g_cls = NCLS - 1;
             if (rc) return rc;
         }
+        return TTSK_OK;
+    };
+
+    // ---- the schedule.  Right chain on the caller's stream, left chain on the helper `aux`, steps enqueued
+    // alternately (neither chain waits for the host to have queued the other: 335 -> 319 us for one C3 tensor); a
+    // join; then Psi / Omega dealt over the two streams.  (Starting Psi_mu / Omega_mu on a third stream as soon as
+    // left step mu and right step d-2-mu are done was measured too: 325 us eager, 377 us replayed from a hipGraph,
+    // slower for 6-8 tensors -- the early products compete with the chain steps for the CUs.  Not kept.)
+    CK(ttsk_stream_wait(aux, stream));   // fork
+    for (int t = 0; t < d; ++t) {
+        if (t < d - 1) CK(right_step(t));
+        CK(left_step(t));
     }
+    // both chains are needed from here on, on both streams
+    CK(ttsk_stream_wait(stream, aux));
+    CK(ttsk_stream_wait(aux, stream));
+    for (int mu = 0; mu < d; ++mu) CK(psi_omega(mu, (mu & 1) ? aux : stream));
     CK(ttsk_stream_wait(stream, aux));   // join
-#undef CK
     return TTSK_OK;
+#undef CK
 }
 
 }  // extern "C"
