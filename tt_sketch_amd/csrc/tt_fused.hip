@@ -269,6 +269,18 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     tot += blk(nb * szTR);
     const size_t szP0 = even((size_t)n[0] * (r_hi[d - 2] - r_lo[d - 2])), offP0 = tot;   // sum mode: Psi_0 per tensor
     if (sum) tot += blk(nb * szP0);
+    // sum mode, larger TT ranks: Psi_mu per tensor (the streamed kernel), then one sum -- faster than the generic
+    // tiles on a contracted index of nb * s (measured: s = 60, 100); one block per stream of the Psi phase
+    static const int sum_psi_split = [] { const char *e = getenv("TTSK_SUM_PSI_SPLIT"); return e ? atoi(e) : 48; }();
+    size_t szPs = 0;
+    if (sum)
+        for (int mu = 1; mu < d - 1; ++mu)
+            if (s[mu + 1] > sum_psi_split) {
+                const size_t v = even((size_t)(l_hi[mu - 1] - l_lo[mu - 1]) * n[mu] * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]));
+                szPs = v > szPs ? v : szPs;
+            }
+    const size_t offPs = tot;
+    tot += 2 * blk(nb * szPs);
     double *ws0 = (double *)scratch(stream, SCRATCH_DRIVER, tot * 8);
     if (!ws0) return TTSK_ERR_HIP;
     auto Lp = [&](int b, int mu) { return ws0 + offL[mu] + (size_t)b * szL[mu]; };
@@ -440,7 +452,17 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                 return t_inter[mu] ? ws0 + offT[mu] + (size_t)(l_lo[mu - 1] * nn) * ldt + (size_t)b * sp
                                    : Tp0(b, mu) + (size_t)(l_lo[mu - 1] * nn) * sp;
             };
-            if (mu < d - 1 && sum) {
+            if (mu < d - 1 && sum && sp > sum_psi_split) {
+                double *blk0 = ws0 + offPs + (size_t)(mu & 1) * blk(nb * szPs);
+                for (int b = 0; b < nb; ++b) { p.A[b] = Tm(b); p.B[b] = Rm(b); p.C[b] = blk0 + (size_t)b * szPs; }
+                StreamSmallArgs ss{nb, (int)(l * nn), (int)sp, (int)r, p.A, ldt, p.B, ldr, p.C, r, 0};
+                g_cls = 4;
+                const int fz = (l * nn < (1ll << 30)) ? stream_small_try(ss, q, stq) : 0;
+                g_cls = NCLS - 1;
+                if (fz < 0) return fz;
+                if (fz == 0) CK(gemm_batch(4, nb, desc2(l * nn, r, 1, sp, ldt, 0, 1, 0, ldr, 1, r, 1, 0), p, q, stq));
+                CK(ttsk_sum_slices(out + psi_at[mu], blk0, nb, szPs, (size_t)(l * nn * r), accumulate, q));
+            } else if (mu < d - 1 && sum) {
                 // Psi[(q,k), c] = sum_{b, p'} T_b[(q,k), p'] R_b[p', c]: (b, p') is one contracted index when both
                 // operands hold the tensors behind one another, a two-level one otherwise
                 if (t_inter[mu] && packedR(jr))
