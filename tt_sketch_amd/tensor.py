@@ -195,6 +195,10 @@ class SparseTensor(Tensor):
     def _upload(self):
         if self._dev is None:
             idx = np.ascontiguousarray(np.asarray(self.indices), dtype=np.int64)
+            # the device kernels address cores, Psi slices and sample tables by these values: out of range
+            # is a memory fault there, so it is an error here (the reference would raise IndexError in its slicing)
+            if idx.size and (idx.min() < 0 or (idx.max(axis=1) >= np.asarray(self.shape, dtype=np.int64)).any()):
+                raise IndexError(f"SparseTensor: an index lies outside the shape {self.shape}")
             # rows are stored in the order of the *first* upload; later views permute
             inv = np.argsort(self._order)
             self._dev = (DevArray.from_host(idx[inv], dtype=np.int64),
