@@ -110,8 +110,12 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
                                                            int64_t r, int transposed, double *Wc,
                                                            double *V, double rcond, double *P,
                                                            int *rank_out, double *svd_US,
-                                                           double *svd_S, double *svd_Vt)
+                                                           double *svd_S, double *svd_Vt,
+                                                           const int *run_if_nonzero = nullptr)
 {
+    // queued behind the normal-equations attempt without the host having looked at its verdict (ttsk_pinv_end):
+    // nothing to do if that attempt was accepted
+    if (run_if_nonzero && *run_if_nonzero == 0) return;
     const int mW = (int)(transposed ? r : l), nW = (int)(transposed ? l : r);
     // LM = 1: W lives in LDS, 2: W and V (the global scratch is then unused).  A template parameter, not a
     // run-time switch: a pointer that may be LDS or global compiles to FLAT loads and stores (67 + 54 of them
@@ -543,17 +547,27 @@ static int *pinv_host_status()
     return p;
 }
 static int g_pinv_began[TTSK_NUM_STREAMS];
+// the verdict of the attempt on the device, outside the scratch arena (which the Jacobi fallback reuses)
+static int *pinv_dev_status(int stream)
+{
+    static int *p = [] {
+        int *q = nullptr;
+        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) q = nullptr;
+        return q;
+    }();
+    return p ? p + stream : nullptr;
+}
 
 // 1 = attempt queued, 0 = not applicable, < 0 = error
 static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st)
 {
     const int n = (int)(l <= r ? l : r);
     int *hs = pinv_host_status();
-    if (n > 128 || !hs) return 0;
+    int *status = pinv_dev_status(stream);
+    if (n > 128 || !hs || !status) return 0;
     double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(3 * n * n + 16) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *G = ws, *Rinv = ws + n * n, *Ginv = ws + 2 * n * n;
-    int *status = (int *)(ws + 3 * n * n);
     int rc;
     if (l <= r) rc = small_gemm(l, l, r, omega, r, 1, omega, 1, r, G, stream);          // Omega Omega^T
     else        rc = small_gemm(r, r, l, omega, 1, r, omega, r, 1, G, stream);          // Omega^T Omega
@@ -673,13 +687,20 @@ int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, d
     const int64_t mW = transposed ? r : l, nW = transposed ? l : r;
     TTSK_ARG(nW <= 1024, "ttsk_pinv: min(l, r) = %lld > 1024 unsupported", (long long)nW);
     rcond = pinv_rcond(l, r, rcond);
+    const int *predicate = nullptr;
     if (g_pinv_began[stream]) {
         g_pinv_began[stream] = 0;
-        const int fr = pinv_cholesky_verdict(l, r, stream, st);
-        if (fr < 0) return fr;
-        if (fr == 1) {
-            if (host_rank) *host_rank = (int)(l < r ? l : r);
-            return TTSK_OK;
+        if (!host_rank) {
+            // nobody waits for the rank: the Jacobi kernel is queued behind the attempt and returns at once if the
+            // attempt was accepted -- no read-back, the stream keeps running (to_tt: d - 1 of these per call)
+            predicate = pinv_dev_status(stream);
+        } else {
+            const int fr = pinv_cholesky_verdict(l, r, stream, st);
+            if (fr < 0) return fr;
+            if (fr == 1) {
+                *host_rank = (int)(l < r ? l : r);
+                return TTSK_OK;
+            }
         }
     }
     const size_t ws_elems = (size_t)(mW * nW + nW * nW) + 1;
@@ -692,7 +713,7 @@ int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, d
     auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_omega, l, r, transposed, ws,
                        ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr, (double *)nullptr,
-                       (double *)nullptr, (double *)nullptr);
+                       (double *)nullptr, (double *)nullptr, predicate);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && host_rank) {
         e = hipMemcpyAsync(host_rank, drank, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -728,7 +749,7 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
     if (jm < 0) return TTSK_ERR_HIP;
     auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
-                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt);
+                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt, (const int *)nullptr);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
