@@ -509,22 +509,22 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     // X[i][c] = -(sum_{i < k <= c} R[i][k] X[k][c]) / R[i][i]; four lanes share a column's sum.  (One thread
     // per COLUMN doing its whole back substitution was 50 lanes of one wave walking 1200 dependent LDS round
     // trips: 0.1 ms at n = 50.)
+    // A column of X depends on R and on itself only, and a quad of lanes OWNS its columns (c = quad, quad + 64): the
+    // whole back substitution of a column runs inside one wavefront, in order, without a single workgroup barrier
+    // (a barrier per row, with the columns re-dealt every row, before: 65 -> 61 us at n = 50).
     const int q4 = tid & 3, col4 = tid >> 2;
-    for (int i = n - 2; i >= 0; --i) {
-        const double *ri = A + i * ld;
-        for (int c0 = i + 1; c0 < n; c0 += 64) {
-            const int c = c0 + col4;
+    for (int c = col4; c < n; c += 64) {
+        const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
+        for (int i = c - 1; i >= 0; --i) {
+            const double *ri = A + i * ld;
             double acc = 0.0;
-            if (c < n) {
-                const double *xc = A + c * ld;                          // X[k][c] at A[c][k], k < c
-                for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
-            }
+            for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
-            if (c < n && q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
+            if (q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
         }
-        __syncthreads();
     }
+    __syncthreads();
     // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, c = e - i * n;
