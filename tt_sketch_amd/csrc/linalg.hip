@@ -476,14 +476,16 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     // square root by one thread + scaling of row j + update were three barriers and a serial stretch per
     // column: 75 of the kernel's 118 us at n = 50.)
     int bad = 0;
-    double rmin = 1e300, rmax = 0.0;
+    double pmin = 1e300, pmax = 0.0;                 // pivots r_j^2: the square root is not needed in the loop
     const int ti = tid >> 4, tc = tid & 15;
     for (int j = 0; j < n; ++j) {
         double piv = A[j * ld + j];
         if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-        const double r = sqrt(piv), pinv = 1.0 / piv;
-        rmin = r < rmin ? r : rmin;
-        rmax = r > rmax ? r : rmax;
+        double pinv = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (full division is ~4x the
+        pinv = pinv * (2.0 - piv * pinv);            // instructions, on the critical path of every column)
+        pinv = pinv * (2.0 - piv * pinv);
+        pmin = piv < pmin ? piv : pmin;
+        pmax = piv > pmax ? piv : pmax;
         const double *rj = A + j * ld;
         for (int i = j + 1 + ti; i < n; i += 16) {
             const double f = rj[i] * pinv;
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         }
         __syncthreads();
     }
-    if (tid == 0) status[0] = (bad || rmin < cond_tol * rmax) ? 1 : 0;
+    if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
     // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
     for (int e = tid; e < n * n; e += 256) {
         const int j = e / n, c = e - j * n;
