@@ -191,3 +191,18 @@ print("clean")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
     assert "clean" in out.stdout
+
+
+def test_test_tensor_generators():
+    """hilbert_tensor / sqrt_tensor (reference utils.py:20-39) from their definitions, incl. the swapped first two
+    modes of sqrt_tensor (np.meshgrid's 'xy' default in the reference)."""
+    from tt_sketch_amd import utils
+    H = utils.hilbert_tensor(3, 4)
+    i, j, k = np.ogrid[:4, :4, :4]
+    assert H.shape == (4, 4, 4) and np.array_equal(H, 1.0 / (i + j + k + 1.0))
+    S = utils.sqrt_tensor((3, 4, 5), a=0.5, b=3)
+    assert S.shape == (4, 3, 5) and abs(np.linalg.norm(S) - 1) < 1e-14
+    t = [np.linspace(0.5, 3, n) for n in (4, 3, 5)]
+    want = np.sqrt(np.abs(t[0][:, None, None] + t[1][None, :, None] + t[2][None, None, :]))
+    assert np.allclose(S, want / np.linalg.norm(want), rtol=1e-15, atol=0)
+    assert utils.sqrt_tensor((7,)).shape == (7,)

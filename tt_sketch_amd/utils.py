@@ -136,3 +136,52 @@ def random_normal_dev(shape, seed=None, scale: float = 1.0, stream=0) -> DevArra
 
 def random_normal(shape, seed=None) -> npt.NDArray[np.float64]:
     return random_normal_dev(shape, seed).get()
+
+
+# ---------------------------------------------------------------------------
+# Test-tensor generators and the oblique projector of the reference's utils.py (:20-60, :112-118): what its
+# scripts and experiments build their inputs from.  Host data (they ARE the inputs); the projector's
+# pseudo-inverse and products run on the device.
+def hilbert_tensor(n_dims: int, size: int) -> npt.NDArray:
+    """X[i_1, ..., i_d] = 1 / (i_1 + ... + i_d + 1)."""
+    total = np.zeros((size,) * n_dims)
+    for axis in range(n_dims):
+        total = total + np.arange(size).reshape([size if a == axis else 1 for a in range(n_dims)])
+    return 1.0 / (total + 1.0)
+
+
+def sqrt_tensor(shape: Tuple[int, ...], a=-0.2, b=2) -> npt.NDArray:
+    """sqrt(|t_1 + ... + t_d|) on the grid t_mu = linspace(a, b, n_mu), scaled to Frobenius norm 1.  As in the
+    reference (whose ``np.meshgrid`` default is 'xy' indexing) the result has its first two modes swapped:
+    shape (n_2, n_1, n_3, ...)."""
+    shape = tuple(shape)
+    if len(shape) >= 2:
+        shape = (shape[1], shape[0]) + shape[2:]
+    d = len(shape)
+    total = np.zeros(tuple(shape))
+    for axis, n in enumerate(shape):
+        total = total + np.linspace(a, b, n).reshape([n if k == axis else 1 for k in range(d)])
+    X = np.sqrt(np.abs(total))
+    return X / np.linalg.norm(X)
+
+
+def power_decay_tensor(shape: Tuple[int, ...], pow: float = 2.0, seed=None) -> npt.NDArray:
+    """A Gaussian tensor whose mode-mu unfoldings get their singular values, scaled to sigma_1 = 1, multiplied by
+    k^(-pow) -- one mode after the other, as in the reference."""
+    sub = np.random.SeedSequence(seed).generate_state(1)[0]
+    A = random_normal(tuple(shape), seed=int(sub))
+    for mode in range(A.ndim):
+        M = matricize(A, mode)
+        U, S, Vt = np.linalg.svd(M, full_matrices=False)
+        S = (S / S[0]) / np.arange(1, S.size + 1) ** pow
+        A = dematricize((U * S) @ Vt, mode, A.shape)
+    return A
+
+
+def projector(X: npt.NDArray, Y=None) -> npt.NDArray:
+    """The oblique projector P_{X,Y} = X (Y^T X)^+ Y^T (Y = X: the orthogonal projector onto range(X))."""
+    Xd = as_dev(X)
+    Yd = Xd if Y is None else as_dev(Y)
+    core = pinv_dev(contract("ki,kj->ij", Yd, Xd))
+    out = contract("ij,kj->ik", contract("ij,jk->ik", Xd, core), Yd)
+    return _like_input(out, X, X if Y is None else Y)
