@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -88,10 +89,20 @@ class RcclComm:
             nat.call("ttsk_comm_unique_id", uid)
         raw = broadcast_bytes(bytes(uid.raw) if rank == 0 else None)
         uid = (ctypes.c_char * 128).from_buffer_copy(raw)
-        nat.call("ttsk_comm_init", uid, rank, world)
         self.rank, self.world = rank, world
         self._scalar = None
         self._rdv = None
+        # RCCL writes a version banner to STDOUT when a communicator comes up; a caller's stdout (bench.py: one JSON
+        # line) is not the library's to write to -- it goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            nat.call("ttsk_comm_init", uid, rank, world)
+            self.max_over_ranks(0.0)          # first collective: whatever RCCL sets up (and prints) lazily
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     @classmethod
     def from_env(cls, device: Optional[int] = None) -> "RcclComm":
