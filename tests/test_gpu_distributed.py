@@ -137,3 +137,54 @@ def test_pool_does_not_recycle_across_streams():
     w = DevArray.empty((1000,))
     assert pt in (v.buf.ptr, w.buf.ptr)         # after the sync both are back
     assert np.allclose(C3.get(), A.get() @ B.get())
+
+
+TWO_RANKS = r"""
+import numpy as np, os, sys
+sys.path.insert(0, %(root)r)
+import tt_sketch_amd as tsa
+from tt_sketch_amd.distributed import HostComm, blocked_stream_sketch_sharded, stream_sketch_sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+comm = HostComm.over_files(rank, world, os.environ["TTSK_RDV_DIR"])
+rng = np.random.default_rng(11)                          # same data on every rank
+shape, l, r = (30, 24, 28, 26), (6, 7, 6), (9, 10, 9)
+terms = [tsa.TensorTrain.random(shape, 5, seed=40 + i) for i in range(7)]
+whole = tsa.TensorSum(terms)
+left = tsa.TensorTrainDRM(l, shape, False, seed=1)
+right = tsa.TensorTrainDRM(r, shape, True, seed=2)
+stt = stream_sketch_sharded(whole, l, r, comm, left_drm=left, right_drm=right)      # 4 + 3 terms, HIP path on both
+ref = tsa.general_sketch(whole, left, right, tsa.SketchMethod.streaming)
+err = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(stt.Psi_cores + stt.Omega_mats, ref.Psi_cores + ref.Omega_mats))
+assert err < 1e-12, err
+idx = np.stack([rng.integers(0, n, 4000) for n in shape]).astype(np.int64)
+sp = tsa.SparseTensor(shape, idx, rng.standard_normal(4000))
+a = stream_sketch_sharded(sp, l, r, comm, seed=33, left_drm_type=tsa.SparseGaussianDRM)   # nnz shards
+b = tsa.stream_sketch(sp, l, r, seed=33, left_drm_type=tsa.SparseGaussianDRM)
+err = max(np.linalg.norm(x - y) / np.linalg.norm(y) for x, y in zip(a.Psi_cores + a.Omega_mats, b.Psi_cores + b.Omega_mats))
+assert err < 1e-12, err
+hl = tsa.SparseGaussianDRM((4, 5, 4), shape, False, seed=21)
+hr = tsa.SparseGaussianDRM((6, 7, 6), shape, True, seed=22)
+blk = blocked_stream_sketch_sharded(sp, hl, hr, [(0, 0, 0), (2, 2, 1), (4, 5, 4)], [(0, 0, 0), (3, 4, 2), (6, 7, 6)], comm)
+one = tsa.general_sketch(sp, hl, hr, tsa.SketchMethod.streaming)
+err = max(np.linalg.norm(x - y) / np.linalg.norm(y) for x, y in zip(blk.Psi_cores + blk.Omega_mats, one.Psi_cores + one.Omega_mats))
+assert err < 1e-12, err
+comm.close()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_processes_share_the_work(tmp_path):
+    """Two ranks, each its own process with the HIP path on the one GPU of the box, the collectives through files
+    (RCCL refuses two ranks on one device): the sharded entry points give the single-process sketch."""
+    env = dict(os.environ, WORLD_SIZE="2", TTSK_RDV_DIR=str(tmp_path / "rdv"))
+    procs = [subprocess.Popen([sys.executable, "-c", TWO_RANKS % dict(root=ROOT)], cwd=ROOT, text=True,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, RANK=str(r)))
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            so, se = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank did not finish")
+        assert p.returncode == 0 and f"rank {r} ok" in so, (so[-300:], se[-2000:])

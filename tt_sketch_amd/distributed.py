@@ -67,6 +67,28 @@ class HostComm:
         self.rank, self.world = int(rank), int(world)
         self._allreduce, self._allgather = allreduce, allgather
 
+    @classmethod
+    def over_files(cls, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0) -> "HostComm":
+        """Collectives of one node through ``FileRendezvous`` (host buffers written to a shared directory): for
+        launches without RCCL -- several ranks on ONE GPU in the tests, or a host-only rehearsal.  Not a fast path:
+        every rank reads every other rank's buffer."""
+        from .rendezvous import FileRendezvous
+        rdv = FileRendezvous(rank, world, directory, timeout)
+
+        def gather(buf):
+            return [np.frombuffer(b, dtype=np.float64).copy() for b in rdv.allgather(np.ascontiguousarray(buf).tobytes())]
+
+        def reduce(buf):
+            parts = gather(buf)
+            out = parts[0]
+            for p in parts[1:]:
+                out = out + p                      # rank order: every rank forms the same sum
+            return out.reshape(np.shape(buf))
+
+        comm = cls(rank, world, reduce, gather)
+        comm.close = rdv.close
+        return comm
+
     def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
         return np.asarray(self._allreduce(np.ascontiguousarray(buf, dtype=np.float64)))
 
