@@ -190,6 +190,10 @@ int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *
  * reference's streams are not reproducible across hosts, parity is by
  * injection; this generator is the same hash -> ndtri construction keyed by (seed, i). */
 int ttsk_fill_normal(double *dev_out, size_t n, uint64_t seed, double scale, int stream);
+/* `count` such fills in one launch -- array i gets exactly the samples ttsk_fill_normal(seeds[i], scales[i]) would
+ * give it (the d - 1 cores of a TensorTrainDRM, tensor.py:358-371: one launch instead of d - 1).  Host arrays. */
+int ttsk_fill_normal_many(int count, double *const *dev_outs, const size_t *ns, const uint64_t *seeds,
+                          const double *scales, int stream);
 
 /* ---- sparse-input kernels --------------------------------------------------
  * TensorTrainDRM.sketch_sparse (tensor_train_drm.py:60-69): per nonzero e,

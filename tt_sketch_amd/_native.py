@@ -73,6 +73,7 @@ def _bind(lib):
         "ttsk_sparse_normal_dev": [P, c_int64, POINTER(I), POINTER(c_uint64), I, S, I, I, c_uint64, P, I],
         "ttsk_sparse_sign_dev": [P, c_int64, POINTER(I), POINTER(c_uint64), I, S, I, I, I, I, c_uint64, P, I],
         "ttsk_fill_normal": [P, S, c_uint64, c_double, I],
+        "ttsk_fill_normal_many": [I, POINTER(P), POINTER(S), POINTER(c_uint64), POINTER(c_double), I],
         "ttsk_sparse_ttdrm_step": [P, c_int64, P, c_int64, c_int64, P, S, P, I],
         "ttsk_sparse_densedrm_gather": [P, c_int64, c_int64, P, c_int64, POINTER(I), POINTER(c_int64), I, S, P, I],
         "ttsk_sparse_psi": [P, P, P, S, P, c_int64, P, c_int64, c_int64, P, I],
@@ -136,7 +137,7 @@ _dirty = set()
 _STREAM_LAST = frozenset((
     "ttsk_memset", "ttsk_d2d", "ttsk_gemm", "ttsk_copy_strided", "ttsk_axpby", "ttsk_sum_slices",
     "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
-    "ttsk_fill_normal", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
+    "ttsk_fill_normal", "ttsk_fill_normal_many", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
     "ttsk_sparse_sort_mode", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
     "ttsk_qr_thin", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
 _BLOCKING = frozenset(("ttsk_h2d", "ttsk_d2h"))          # return only after their stream has drained

@@ -290,7 +290,7 @@ __global__ void sign_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t
     for (int j = 0; j < w; ++j) out[e * (size_t)w + j] = (OUT)ws[(size_t)(rank_min + j) * N + e];
 }
 
-__global__ __launch_bounds__(256) void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
+__device__ __forceinline__ void fill_normal_body(double *out, size_t n, uint64_t key, double scale)
 {
     constexpr int PER = 8;                                   // samples per thread and tile
     __shared__ double tile[256 * PER];
@@ -320,6 +320,25 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(double *out, size_t n,
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(double *out, size_t n, uint64_t key, double scale)
+{
+    fill_normal_body(out, n, key, scale);
+}
+
+// several independent fills in one launch (the d - 1 cores of a TensorTrainDRM): blockIdx.y picks the array
+constexpr int FILL_MANY_MAX = 32;
+struct FillMany {
+    double *out[FILL_MANY_MAX];
+    size_t n[FILL_MANY_MAX];
+    uint64_t key[FILL_MANY_MAX];
+    double scale[FILL_MANY_MAX];
+};
+__global__ __launch_bounds__(256) void fill_normal_many_kernel(FillMany a)
+{
+    const int seg = blockIdx.y;
+    fill_normal_body(a.out[seg], a.n[seg], a.key[seg], a.scale[seg]);
 }
 
 static unsigned grid_for(size_t n, unsigned block = 256, unsigned cap = 16384)
@@ -523,6 +542,29 @@ int ttsk_fill_normal(double *dev_out, size_t n, uint64_t seed, double scale, int
     hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for(n, 2048, 1u << 16)), dim3(256), 0, st, dev_out, n,
                        key, scale);
     TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_fill_normal_many(int count, double *const *dev_outs, const size_t *ns, const uint64_t *seeds,
+                          const double *scales, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(count >= 0 && (count == 0 || (dev_outs && ns && seeds && scales)), "ttsk_fill_normal_many: bad argument");
+    for (int c0 = 0; c0 < count; c0 += FILL_MANY_MAX) {
+        const int cnt = count - c0 < FILL_MANY_MAX ? count - c0 : FILL_MANY_MAX;
+        FillMany a{};
+        size_t nmax = 0;
+        for (int i = 0; i < cnt; ++i) {
+            a.out[i] = dev_outs[c0 + i];
+            a.n[i] = ns[c0 + i];
+            a.key[i] = mix64(seeds[c0 + i] ^ 0x9E3779B97F4A7C15ULL);      // as ttsk_fill_normal: the same samples
+            a.scale[i] = scales[c0 + i];
+            nmax = a.n[i] > nmax ? a.n[i] : nmax;
+        }
+        if (nmax == 0) continue;
+        hipLaunchKernelGGL(fill_normal_many_kernel, dim3(grid_for(nmax, 2048, 1u << 14), (unsigned)cnt), dim3(256), 0, st, a);
+        TTSK_LAUNCH_CHECK();
+    }
     return TTSK_OK;
 }
 

@@ -18,7 +18,7 @@ from ..device import DevArray, as_dev, contract
 from ..drm_base import CanSlice, handle_transpose
 from ..sketching_methods.abstract_methods import (CansketchCP, CansketchDense, CansketchSparse,
                                                   CansketchTT, CanSketchTucker)
-from ..utils import random_normal_dev
+from ..utils import random_normal_dev_many
 
 
 class TensorTrainDRM(CansketchSparse, CansketchTT, CansketchCP, CanSlice, CansketchDense,
@@ -33,11 +33,10 @@ class TensorTrainDRM(CansketchSparse, CansketchTT, CansketchCP, CanSlice, Canske
         else:
             walk = self.shape[::-1] if transpose else self.shape
             rk = (1,) + tuple(self.true_rank)
-            self.cores = [
-                random_normal_dev((rk[mu], walk[mu], rk[mu + 1]),
-                                  seed=(self.seed << 20) + mu, scale=1.0 / np.sqrt(rk[mu]))
-                for mu in range(len(walk) - 1)
-            ]
+            k = len(walk) - 1
+            self.cores = random_normal_dev_many([(rk[mu], walk[mu], rk[mu + 1]) for mu in range(k)],
+                                                [(self.seed << 20) + mu for mu in range(k)],
+                                                [1.0 / np.sqrt(rk[mu]) for mu in range(k)])
         self._dev: List[DevArray] = []
         self._dev_src: list = []          # the host objects the device copies were made from
 

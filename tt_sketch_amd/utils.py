@@ -134,6 +134,18 @@ def random_normal_dev(shape, seed=None, scale: float = 1.0, stream=0) -> DevArra
     return out
 
 
+def random_normal_dev_many(shapes, seeds, scales, stream=0):
+    """Several ``random_normal_dev`` arrays from ONE launch (``ttsk_fill_normal_many``); array i holds exactly
+    what ``random_normal_dev(shapes[i], seeds[i], scales[i])`` would."""
+    outs = [DevArray.empty(tuple(sh), stream=stream) for sh in shapes]
+    k = len(outs)
+    if k:
+        nat.call("ttsk_fill_normal_many", k, (ctypes.c_void_p * k)(*[o.ptr for o in outs]),
+                 (ctypes.c_size_t * k)(*[o.size for o in outs]), (ctypes.c_uint64 * k)(*[int(s) % 2**64 for s in seeds]),
+                 (ctypes.c_double * k)(*[float(c) for c in scales]), stream)
+    return outs
+
+
 def random_normal(shape, seed=None) -> npt.NDArray[np.float64]:
     return random_normal_dev(shape, seed).get()
 
