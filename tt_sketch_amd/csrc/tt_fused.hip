@@ -427,7 +427,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             p += (l_hi[mu] - l_lo[mu]) * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]);
         }
     }
-    auto psi_omega = [&](int mu, int q) -> int {
+    auto psi_omega = [&](int mu, int q, bool do_psi = true, bool do_omega = true) -> int {
         const int64_t sp = s[mu + 1], nn = n[mu];
         hipStream_t stq = stream_of(q);
         // right contraction of modes mu+1.. : Rc[j] with j = d-2-mu, columns [r_lo, r_hi)
@@ -435,7 +435,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
         const int64_t ldr = mu < d - 1 ? rt[jr + 1] : 0, r = mu < d - 1 ? r_hi[jr] - r_lo[jr] : 1;
         auto Rm = [&](int b) { return Rp(b, jr) + r_lo[jr]; };
         BatchPtrs p{};
-        if (mu == 0 && sum) {
+        if (!do_psi) {
+        } else if (mu == 0 && sum) {
             // the cores X_b,0 are anywhere in memory: per-tensor products into the workspace, then one sum
             for (int b = 0; b < nb; ++b) { p.A[b] = Xc(b, 0); p.B[b] = Rm(b); p.C[b] = ws0 + offP0 + (size_t)b * szP0; }
             CK(gemm_batch(5, nb, desc2(nn, r, 1, sp, sp, 0, 1, 0, ldr, 1, r, 1, 0), p, q, stq));
@@ -494,7 +495,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                 }
             }
         }
-        if (mu < d - 1) {
+        if (mu < d - 1 && do_omega) {
             const int64_t l = l_hi[mu] - l_lo[mu];
             if (sum) {
                 // Omega[q, c] = sum_{b, p} L_b[p, q] R_b[p, c]
@@ -532,7 +533,50 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     // both chains are needed from here on, on both streams
     CK(ttsk_stream_wait(stream, aux));
     CK(ttsk_stream_wait(aux, stream));
-    for (int mu = 0; mu < d; ++mu) CK(psi_omega(mu, (mu & 1) ? aux : stream));
+    // Few tensors of one shape in every mode (one C3 tensor: 4 Psi, 5 Omega of equal shapes): the interior Psi
+    // products as ONE launch of the streamed kernel, all Omega as one batched launch -- the tail after the chains is
+    // then two launches deep on either stream instead of five.
+    bool grouped = !sum && d >= 4 && nb * (d - 1) <= SK_MAXB;
+    for (int mu = 1; mu < d - 1 && grouped; ++mu)
+        grouped = n[mu] == n[1] && s[mu] == s[1] && s[mu + 1] == s[1] && t_inter[mu] == t_inter[1] &&
+                  l_hi[mu - 1] - l_lo[mu - 1] == l_hi[0] - l_lo[0] && lt[mu] == lt[1] && lt[mu + 1] == lt[1] &&
+                  r_hi[d - 2 - mu] - r_lo[d - 2 - mu] == r_hi[0] - r_lo[0] && rt[d - 1 - mu] == rt[1];
+    grouped = grouped && s[d - 1] == s[1] && l_hi[d - 2] - l_lo[d - 2] == l_hi[0] - l_lo[0] && lt[d - 1] == lt[1] &&
+              r_hi[d - 2] - r_lo[d - 2] == r_hi[0] - r_lo[0] && rt[d - 1] == rt[1];
+    if (grouped) {
+        const int64_t sp = s[1], nn = n[1], l = l_hi[0] - l_lo[0], r = r_hi[0] - r_lo[0], ldr = rt[1];
+        const int64_t ldt = t_inter[1] ? (int64_t)nb * sp : sp;
+        BatchPtrs p{};
+        int cnt = 0;
+        for (int mu = 1; mu < d - 1; ++mu)
+            for (int b = 0; b < nb; ++b, ++cnt) {
+                const int jr = d - 2 - mu;
+                p.A[cnt] = t_inter[mu] ? ws0 + offT[mu] + (size_t)(l_lo[mu - 1] * nn) * ldt + (size_t)b * sp
+                                       : Tp0(b, mu) + (size_t)(l_lo[mu - 1] * nn) * sp;
+                p.B[cnt] = Rp(b, jr) + r_lo[jr];
+                p.C[cnt] = outb(b) + psi_at[mu];
+            }
+        StreamSmallArgs ss{cnt, (int)(l * nn), (int)sp, (int)r, p.A, ldt, p.B, ldr, p.C, r, accumulate};
+        g_cls = 4;
+        const int fz = (l * nn < (1ll << 30)) ? stream_small_try(ss, stream, st) : 0;
+        g_cls = NCLS - 1;
+        if (fz < 0) return fz;
+        if (fz == 0) grouped = false;                 // shape outside the streamed kernel's cover: mode by mode
+        else {
+            BatchPtrs o{};
+            cnt = 0;
+            for (int mu = 0; mu < d - 1; ++mu)
+                for (int b = 0; b < nb; ++b, ++cnt) {
+                    const int jr = d - 2 - mu;
+                    o.A[cnt] = Lp(b, mu) + l_lo[mu]; o.B[cnt] = Rp(b, jr) + r_lo[jr]; o.C[cnt] = outb(b) + om_at[mu];
+                }
+            CK(gemm_batch(5, cnt, desc2(l, r, 1, sp, 1, 0, lt[1], 0, ldr, 1, r, 1, accumulate), o, aux, st_aux));
+            CK(psi_omega(0, aux, true, false));
+            CK(psi_omega(d - 1, stream, true, false));
+        }
+    }
+    if (!grouped)
+        for (int mu = 0; mu < d; ++mu) CK(psi_omega(mu, (mu & 1) ? aux : stream));
     CK(ttsk_stream_wait(stream, aux));   // join
     return TTSK_OK;
 #undef CK
