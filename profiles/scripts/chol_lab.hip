@@ -1,0 +1,143 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <random>
+#include <cmath>
+template <int CTRL> __device__ __forceinline__ double quad_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
+                                                       double *__restrict__ Ginv, int *__restrict__ status,
+                                                       double cond_tol, long long *stamps)
+{
+#define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+    STAMP(0);
+    extern __shared__ double sm[];
+    const int ld = n + 1, tid = threadIdx.x;
+    double *A = sm;
+    double *xd = sm + n * ld;
+    for (int e = tid; e < n * n; e += 256) A[(e / n) * ld + e % n] = G[e];
+    __syncthreads();
+    // Unscaled right-looking recurrence, ONE barrier per column: row j keeps r_j R[j][:] (r_j^2 = pivot) until
+    // the end, the trailing update divides by the pivot instead; every thread reads the pivot itself.  (Pivot
+    // square root by one thread + scaling of row j + update were three barriers and a serial stretch per
+    // column: 75 of the kernel's 118 us at n = 50.)
+    STAMP(1);
+    int bad = 0;
+    double pmin = 1e300, pmax = 0.0;                 // pivots r_j^2: the square root is not needed in the loop
+    const int ti = tid >> 4, tc = tid & 15;
+    for (int j = 0; j < n; ++j) {
+        double piv = A[j * ld + j];
+        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+        double pinv = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (full division is ~4x the
+        pinv = pinv * (2.0 - piv * pinv);            // instructions, on the critical path of every column)
+        pinv = pinv * (2.0 - piv * pinv);
+        pmin = piv < pmin ? piv : pmin;
+        pmax = piv > pmax ? piv : pmax;
+        const double *rj = A + j * ld;
+        for (int i = j + 1 + ti; i < n; i += 16) {
+            const double f = rj[i] * pinv;
+            for (int c = i + tc; c < n; c += 16) A[i * ld + c] = fma(-f, rj[c], A[i * ld + c]);
+        }
+        __syncthreads();
+    }
+    STAMP(2);
+    if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
+    // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
+    for (int e = tid; e < n * n; e += 256) {
+        const int j = e / n, c = e - j * n;
+        if (c == j) xd[j] = 1.0 / sqrt(A[j * ld + j] > 0.0 ? A[j * ld + j] : 1.0);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int j = e / n, c = e - j * n;
+        if (c >= j) A[j * ld + c] *= xd[j];
+    }
+    __syncthreads();
+    // X = R^-1 (upper triangular).  X stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused
+    // strict lower triangle of A at A[c][i], its diagonal to xd[].
+    // Row i of X from the rows below it, all columns c > i at once, one barrier per row:
+    // X[i][c] = -(sum_{i < k <= c} R[i][k] X[k][c]) / R[i][i]; four lanes share a column's sum.  (One thread
+    // per COLUMN doing its whole back substitution was 50 lanes of one wave walking 1200 dependent LDS round
+    // trips: 0.1 ms at n = 50.)
+    STAMP(3);
+    // A column of X depends on R and on itself only, and a quad of lanes OWNS its columns (c = quad, quad + 64): the
+    // whole back substitution of a column runs inside one wavefront, in order, without a single workgroup barrier
+    // (a barrier per row, with the columns re-dealt every row, before: 65 -> 61 us at n = 50).
+    const int q4 = tid & 3, col4 = tid >> 2;
+    for (int c = col4; c < n; c += 64) {
+        const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
+        double xprev = 0.0;                                             // X[i+1][c]: every lane of the quad has it
+        for (int i = c - 1; i >= 0; --i) {
+            const double *ri = A + i * ld;
+            // the newest entry comes from the register (its LDS write may still be in flight), the older ones from LDS
+            double acc0 = (q4 == 0 && i + 1 < c) ? ri[i + 1] * xprev : 0.0, acc1 = 0.0;
+            int k = i + 2 + q4;
+            for (; k + 4 < c; k += 8) { acc0 = fma(ri[k], xc[k], acc0); acc1 = fma(ri[k + 4], xc[k + 4], acc1); }
+            if (k < c) acc0 = fma(ri[k], xc[k], acc0);
+            double acc = acc0 + acc1;
+            acc += quad_dpp<0xB1>(acc);          // lanes 1 0 3 2
+            acc += quad_dpp<0x4E>(acc);          // lanes 2 3 0 1
+            xprev = -(acc + ri[c] * xd[c]) * xd[i];
+            if (q4 == 0) A[c * ld + i] = xprev;
+        }
+    }
+    __syncthreads();
+    STAMP(4);
+    // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        if (i < c) A[i * ld + c] = A[c * ld + i];
+        else if (i == c) A[i * ld + i] = xd[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        if (i > c) A[i * ld + c] = 0.0;
+    }
+    __syncthreads();
+    STAMP(5);
+    for (int e = tid; e < n * n; e += 256) Rinv[e] = A[(e / n) * ld + e % n];
+    STAMP(6);
+    if (Ginv) {
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, c = e - i * n;
+            if (c < i) continue;                                      // symmetric: computed once, written twice
+            const double *xi = A + i * ld, *xc = A + c * ld;
+            double acc0 = 0.0, acc1 = 0.0;
+            int k = c;
+            for (; k + 1 < n; k += 2) {
+                acc0 = fma(xi[k], xc[k], acc0);
+                acc1 = fma(xi[k + 1], xc[k + 1], acc1);
+            }
+            if (k < n) acc0 = fma(xi[k], xc[k], acc0);
+            Ginv[i * n + c] = acc0 + acc1;
+            Ginv[c * n + i] = acc0 + acc1;
+        }
+    }
+    STAMP(7);
+}
+
+int main()
+{
+    for (int n : {50, 100}) {
+        std::mt19937_64 rng(1); std::normal_distribution<double> nd;
+        std::vector<double> B((size_t)n * 2 * n), G((size_t)n * n, 0.0);
+        for (auto &v : B) v = nd(rng);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double a = 0; for (int k = 0; k < 2 * n; ++k) a += B[(size_t)i * 2 * n + k] * B[(size_t)j * 2 * n + k]; G[(size_t)i * n + j] = a; }
+        double *dG, *dR, *dGi; int *dst; long long *dstamp;
+        hipMalloc(&dG, G.size() * 8); hipMalloc(&dR, G.size() * 8); hipMalloc(&dGi, G.size() * 8); hipMalloc(&dst, 4); hipMalloc(&dstamp, 64);
+        hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice);
+        hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, 0, dG, n, dR, dGi, dst, 1e-6, dstamp);
+        hipDeviceSynchronize();
+        long long h[8]; hipMemcpy(h, dstamp, 64, hipMemcpyDeviceToHost);
+        printf("n = %d: load %lld | factor %lld | scale %lld | backsub %lld | denseX %lld | storeR %lld | Ginv %lld | total %lld cycles (100 MHz counter?)\n", n,
+               h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+    }
+    return 0;
+}
