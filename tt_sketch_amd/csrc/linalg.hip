@@ -471,27 +471,49 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     double *xd = sm + n * ld;
     for (int e = tid; e < n * n; e += 256) A[(e / n) * ld + e % n] = G[e];
     __syncthreads();
-    // Unscaled right-looking recurrence, ONE barrier per column: row j keeps r_j R[j][:] (r_j^2 = pivot) until
-    // the end, the trailing update divides by the pivot instead; every thread reads the pivot itself.  (Pivot
-    // square root by one thread + scaling of row j + update were three barriers and a serial stretch per
-    // column: 75 of the kernel's 118 us at n = 50.)
+    // Unscaled right-looking recurrence: row j keeps r_j R[j][:] (r_j^2 = pivot) until the end, the trailing update
+    // divides by the pivot instead, every thread reads the pivots itself.  TWO columns per barrier: the pivot of
+    // column j + 1 and its row after step j follow from rows j and j + 1 alone, so every thread forms them on the
+    // fly and updates its elements with both columns at once; the updated row j + 1 goes through a shadow row (the
+    // others still read the old one) and home after the barrier -- nobody reads it again before the scaling pass.
+    // (History at n = 50: three barriers per column 75 us of 118; one per column 55 k cycles; two columns 42 k.)
     int bad = 0;
     double pmin = 1e300, pmax = 0.0;                 // pivots r_j^2: the square root is not needed in the loop
     const int ti = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < n; ++j) {
+    // hardware reciprocal + two Newton steps (a full division is ~4x the instructions, on the critical path)
+    auto rcp2 = [](double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); };
+    __shared__ double shadow[2 * 128];
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+        const double *r0 = A + j * ld, *r1 = A + (j + 1) * ld;
+        double p0 = r0[j];
+        if (!(p0 > 0.0)) { bad = 1; p0 = 1.0; }
+        const double pi0 = rcp2(p0);
+        const double g = r0[j + 1] * pi0;                      // factor of row j + 1 against row j
+        double p1 = fma(-g, r0[j + 1], r1[j + 1]);             // pivot of column j + 1 after step j
+        if (!(p1 > 0.0)) { bad = 1; p1 = 1.0; }
+        const double pi1 = rcp2(p1);
+        pmin = fmin(pmin, fmin(p0, p1));
+        pmax = fmax(pmax, fmax(p0, p1));
+        for (int i = j + 2 + ti; i < n; i += 16) {
+            const double a0 = r0[i], a1 = fma(-g, a0, r1[i]);  // A[j][i] and A[j+1][i] after step j
+            const double f0 = a0 * pi0, f1 = a1 * pi1;
+            for (int c = i + tc; c < n; c += 16) {
+                const double u1 = fma(-g, r0[c], r1[c]);       // row j + 1 after step j, at c
+                A[i * ld + c] = fma(-f1, u1, fma(-f0, r0[c], A[i * ld + c]));
+            }
+        }
+        double *sh = shadow + ((j >> 1) & 1) * 128;
+        for (int c = j + 1 + tid; c < n; c += 256) sh[c] = fma(-g, r0[c], r1[c]);
+        __syncthreads();
+        for (int c = j + 1 + tid; c < n; c += 256) A[(j + 1) * ld + c] = sh[c];
+    }
+    __syncthreads();
+    if (j < n) {                                               // odd n: the last pivot
         double piv = A[j * ld + j];
         if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-        double pinv = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (full division is ~4x the
-        pinv = pinv * (2.0 - piv * pinv);            // instructions, on the critical path of every column)
-        pinv = pinv * (2.0 - piv * pinv);
-        pmin = piv < pmin ? piv : pmin;
-        pmax = piv > pmax ? piv : pmax;
-        const double *rj = A + j * ld;
-        for (int i = j + 1 + ti; i < n; i += 16) {
-            const double f = rj[i] * pinv;
-            for (int c = i + tc; c < n; c += 16) A[i * ld + c] = fma(-f, rj[c], A[i * ld + c]);
-        }
-        __syncthreads();
+        pmin = fmin(pmin, piv);
+        pmax = fmax(pmax, piv);
     }
     if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
     // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
@@ -521,8 +543,8 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
             const double *ri = A + i * ld;
             double acc = 0.0;
             for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
+            acc += jac_dpp<0xB1>(acc);              // quad_perm 1 0 3 2
+            acc += jac_dpp<0x4E>(acc);              // quad_perm 2 3 0 1
             if (q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
         }
     }
