@@ -563,20 +563,30 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     __syncthreads();
     for (int e = tid; e < n * n; e += 256) Rinv[e] = A[(e / n) * ld + e % n];
     if (Ginv) {
-        for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, c = e - i * n;
-            if (c < i) continue;                                      // symmetric: computed once, written twice
-            const double *xi = A + i * ld, *xc = A + c * ld;
-            double acc0 = 0.0, acc1 = 0.0;
-            int k = c;
-            for (; k + 1 < n; k += 2) {
-                acc0 = fma(xi[k], xc[k], acc0);
-                acc1 = fma(xi[k + 1], xc[k + 1], acc1);
+        // G^-1 = X X^T on the matrix cores: tile (ta, tb), tb >= ta, one per wave and turn, mirrored on the way out;
+        // X is upper triangular, so the sum over k starts at the column tile (22 k -> 11 k cycles at n = 50, 125 k ->
+        // 30 k at n = 100 against one thread per element)
+        const int lane = tid & 63, wv = tid >> 6, x16 = lane & 15, kq = lane >> 4;
+        const int nt = (n + 15) >> 4, nkb = (n + 3) >> 2;
+        int t = 0;
+        for (int ta = 0; ta < nt; ++ta)
+            for (int tb = ta; tb < nt; ++tb, ++t) {
+                if ((t & 3) != wv) continue;
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                const int ra = 16 * ta + x16, rb = 16 * tb + x16;
+                const double *xa = A + ra * ld, *xb = A + rb * ld;
+                for (int kb = 4 * tb; kb < nkb; ++kb) {
+                    const int k = 4 * kb + kq;
+                    const double av = (ra < n && k < n) ? xa[k] : 0.0;
+                    const double bv = (rb < n && k < n) ? xb[k] : 0.0;
+                    acc = mfma16(av, bv, acc);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int i = 16 * ta + kq + 4 * jj, c = 16 * tb + x16;
+                    if (i < n && c < n) { Ginv[i * n + c] = acc[jj]; Ginv[c * n + i] = acc[jj]; }
+                }
             }
-            if (k < n) acc0 = fma(xi[k], xc[k], acc0);
-            Ginv[i * n + c] = acc0 + acc1;
-            Ginv[c * n + i] = acc0 + acc1;
-        }
     }
 }
 
