@@ -90,29 +90,59 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     // A column of X depends on R and on itself only, and a quad of lanes OWNS its columns (c = quad, quad + 64): the
     // whole back substitution of a column runs inside one wavefront, in order, without a single workgroup barrier
     // (a barrier per row, with the columns re-dealt every row, before: 65 -> 61 us at n = 50).
+    // X = R^-1 in 16 x 16 blocks.  (1) the diagonal blocks, all at once: a quad of lanes owns a column and walks up
+    // to 15 rows of its own block; (2) block rows from the bottom: X_ij = -X_ii (sum_{i<k<=j} R_ik X_kj) on the matrix
+    // cores, the accumulator registers of the sum being the B operand of the second product; one barrier per block row.
     const int q4 = tid & 3, col4 = tid >> 2;
     for (int c = col4; c < n; c += 64) {
         const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
-        double xprev = 0.0;                                             // X[i+1][c]: every lane of the quad has it
-        for (int i = c - 1; i >= 0; --i) {
+        const int top = c & ~15;
+        for (int i = c - 1; i >= top; --i) {
             const double *ri = A + i * ld;
-            // the newest entry comes from the register (its LDS write may still be in flight), the older ones from LDS
-            double acc0 = (q4 == 0 && i + 1 < c) ? ri[i + 1] * xprev : 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-            int k = i + 2 + q4;
-            for (; k + 12 < c; k += 16) {
-                const double r0_ = ri[k], r1_ = ri[k + 4], r2_ = ri[k + 8], r3_ = ri[k + 12];
-                const double x0_ = xc[k], x1_ = xc[k + 4], x2_ = xc[k + 8], x3_ = xc[k + 12];
-                acc0 = fma(r0_, x0_, acc0); acc1 = fma(r1_, x1_, acc1); acc2 = fma(r2_, x2_, acc2); acc3 = fma(r3_, x3_, acc3);
-            }
-            for (; k < c; k += 4) acc0 = fma(ri[k], xc[k], acc0);
-            double acc = (acc0 + acc1) + (acc2 + acc3);
-            acc += quad_dpp<0xB1>(acc);          // lanes 1 0 3 2
-            acc += quad_dpp<0x4E>(acc);          // lanes 2 3 0 1
-            xprev = -(acc + ri[c] * xd[c]) * xd[i];
-            if (q4 == 0) A[c * ld + i] = xprev;
+            double acc = 0.0;
+            for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
+            acc += quad_dpp<0xB1>(acc);
+            acc += quad_dpp<0x4E>(acc);
+            if (q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
         }
     }
     __syncthreads();
+    {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, wv = tid >> 6, x16 = lane & 15, kq = lane >> 4;
+        const int nt = (n + 15) >> 4;
+        // X(r, c) for r <= c from its storage (strict upper part transposed into the lower triangle, diagonal in xd)
+        auto Xat = [&](int r, int c) -> double {
+            if (r >= n || c >= n || r > c) return 0.0;
+            return r == c ? xd[c] : A[c * ld + r];
+        };
+        for (int bi = nt - 2; bi >= 0; --bi) {
+            for (int bj = bi + 1 + wv; bj < nt; bj += 4) {
+                v4d S = {0.0, 0.0, 0.0, 0.0};
+                const int ra = 16 * bi + x16;
+                for (int bk = bi + 1; bk <= bj; ++bk)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const int k = 16 * bk + 4 * kb + kq;
+                        const double av = (ra < n && k < n) ? A[ra * ld + k] : 0.0;          // R[ra][k], k > ra
+                        const double bv = Xat(k, 16 * bj + x16);
+                        S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
+                    }
+                v4d Xn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const double av = Xat(16 * bi + x16, 16 * bi + 4 * kb + kq);              // X_ii[m][k]
+                    Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(av, S[kb], Xn, 0, 0, 0);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = 16 * bi + kq + 4 * jj, c = 16 * bj + x16;
+                    if (r < n && c < n) A[c * ld + r] = -Xn[jj];
+                }
+            }
+            __syncthreads();
+        }
+    }
     STAMP(4);
     // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
     for (int e = tid; e < n * n; e += 256) {

@@ -533,13 +533,17 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     // X[i][c] = -(sum_{i < k <= c} R[i][k] X[k][c]) / R[i][i]; four lanes share a column's sum.  (One thread
     // per COLUMN doing its whole back substitution was 50 lanes of one wave walking 1200 dependent LDS round
     // trips: 0.1 ms at n = 50.)
-    // A column of X depends on R and on itself only, and a quad of lanes OWNS its columns (c = quad, quad + 64): the
-    // whole back substitution of a column runs inside one wavefront, in order, without a single workgroup barrier
-    // (a barrier per row, with the columns re-dealt every row, before: 65 -> 61 us at n = 50).
+    // X = R^-1 in 16 x 16 blocks.  (1) The diagonal blocks, all at once: a quad of lanes owns a column and walks the
+    // (up to 15) rows of its own block -- one wavefront per 16 columns, in order, no workgroup barrier.  (2) Block rows
+    // from the bottom: X_ij = -X_ii (sum_{i<k<=j} R_ik X_kj) on the matrix cores; the accumulator registers of the sum
+    // are the B operand of the second product (register kb of a lane holds rows 4 kb + (lane >> 4): exactly k-block
+    // kb); one barrier per block row.  (One column per quad over ALL rows was 42 k of the kernel's 118 k cycles at
+    // n = 50 -- 900 cycles of dependent LDS reads per row -- and 152 k of 396 k at n = 100; now 20 k and 55 k.)
     const int q4 = tid & 3, col4 = tid >> 2;
     for (int c = col4; c < n; c += 64) {
         const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
-        for (int i = c - 1; i >= 0; --i) {
+        const int top = c & ~15;
+        for (int i = c - 1; i >= top; --i) {
             const double *ri = A + i * ld;
             double acc = 0.0;
             for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
@@ -549,6 +553,37 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         }
     }
     __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6, x16 = lane & 15, kq = lane >> 4;
+        const int nt = (n + 15) >> 4;
+        // X(r, c), r <= c, from its storage: strict upper part transposed into the lower triangle, diagonal in xd
+        auto Xat = [&](int r, int c) -> double {
+            if (r >= n || c >= n || r > c) return 0.0;
+            return r == c ? xd[c] : A[c * ld + r];
+        };
+        for (int bi = nt - 2; bi >= 0; --bi) {
+            for (int bj = bi + 1 + wv; bj < nt; bj += 4) {
+                v4d S = {0.0, 0.0, 0.0, 0.0};
+                const int ra = 16 * bi + x16;
+                for (int bk = bi + 1; bk <= bj; ++bk)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const int k = 16 * bk + 4 * kb + kq;
+                        const double av = (ra < n && k < n) ? A[ra * ld + k] : 0.0;          // R[ra][k], k > ra
+                        S = mfma16(av, Xat(k, 16 * bj + x16), S);
+                    }
+                v4d Xn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) Xn = mfma16(Xat(16 * bi + x16, 16 * bi + 4 * kb + kq), S[kb], Xn);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = 16 * bi + kq + 4 * jj, c = 16 * bj + x16;
+                    if (r < n && c < n) A[c * ld + r] = -Xn[jj];
+                }
+            }
+            __syncthreads();
+        }
+    }
     // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, c = e - i * n;
