@@ -70,14 +70,11 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     STAMP(2);
     if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
     // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
-    for (int e = tid; e < n * n; e += 256) {
-        const int j = e / n, c = e - j * n;
-        if (c == j) xd[j] = 1.0 / sqrt(A[j * ld + j] > 0.0 ? A[j * ld + j] : 1.0);
-    }
+    if (tid < n) xd[tid] = 1.0 / sqrt(A[tid * ld + tid] > 0.0 ? A[tid * ld + tid] : 1.0);
     __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int j = e / n, c = e - j * n;
-        if (c >= j) A[j * ld + c] *= xd[j];
+    for (int jj = ti; jj < n; jj += 16) {
+        const double sc = xd[jj];
+        for (int c = jj + tc; c < n; c += 16) A[jj * ld + c] *= sc;
     }
     __syncthreads();
     // X = R^-1 (upper triangular).  X stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused
@@ -144,20 +141,13 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         }
     }
     STAMP(4);
-    // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, c = e - i * n;
-        if (i < c) A[i * ld + c] = A[c * ld + i];
-        else if (i == c) A[i * ld + i] = xd[i];
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, c = e - i * n;
-        if (i > c) A[i * ld + c] = 0.0;
-    }
-    __syncthreads();
     STAMP(5);
-    for (int e = tid; e < n * n; e += 256) Rinv[e] = A[(e / n) * ld + e % n];
+    auto Xe = [&](int r, int c) -> double {          // X(r, c): strict upper part transposed in the lower triangle
+        if (r >= n || c >= n || r > c) return 0.0;
+        return r == c ? xd[c] : A[c * ld + r];
+    };
+    for (int i = ti; i < n; i += 16)
+        for (int c = tc; c < n; c += 16) Rinv[i * n + c] = Xe(i, c);
     STAMP(6);
     if (Ginv) {
         // G^-1 = X X^T on the matrix cores: tile (ti, tc), tc >= ti, one per wave and turn; X is upper triangular,
@@ -171,11 +161,10 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
                 if ((t & 3) != wv) continue;
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 const int ra = 16 * ta + x16, rb = 16 * tb + x16;
-                const double *xa = A + ra * ld, *xb = A + rb * ld;
                 for (int kb = 4 * tb; kb < nkb; ++kb) {
                     const int k = 4 * kb + kq;
-                    const double av = (ra < n && k < n) ? xa[k] : 0.0;
-                    const double bv = (rb < n && k < n) ? xb[k] : 0.0;
+                    const double av = Xe(ra, k);
+                    const double bv = Xe(rb, k);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
 #pragma unroll

@@ -517,22 +517,15 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     }
     if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
     // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
-    for (int e = tid; e < n * n; e += 256) {
-        const int j = e / n, c = e - j * n;
-        if (c == j) xd[j] = 1.0 / sqrt(A[j * ld + j] > 0.0 ? A[j * ld + j] : 1.0);
+    if (tid < n) xd[tid] = 1.0 / sqrt(A[tid * ld + tid] > 0.0 ? A[tid * ld + tid] : 1.0);
+    __syncthreads();
+    for (int jj = ti; jj < n; jj += 16) {
+        const double sc = xd[jj];
+        for (int c = jj + tc; c < n; c += 16) A[jj * ld + c] *= sc;
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int j = e / n, c = e - j * n;
-        if (c >= j) A[j * ld + c] *= xd[j];
-    }
-    __syncthreads();
-    // X = R^-1 (upper triangular).  X stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused
-    // strict lower triangle of A at A[c][i], its diagonal to xd[].
-    // Row i of X from the rows below it, all columns c > i at once, one barrier per row:
-    // X[i][c] = -(sum_{i < k <= c} R[i][k] X[k][c]) / R[i][i]; four lanes share a column's sum.  (One thread
-    // per COLUMN doing its whole back substitution was 50 lanes of one wave walking 1200 dependent LDS round
-    // trips: 0.1 ms at n = 50.)
+    // X = R^-1 stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused strict lower triangle of A at
+    // A[c][i], its diagonal to xd[].
     // X = R^-1 in 16 x 16 blocks.  (1) The diagonal blocks, all at once: a quad of lanes owns a column and walks the
     // (up to 15) rows of its own block -- one wavefront per 16 columns, in order, no workgroup barrier.  (2) Block rows
     // from the bottom: X_ij = -X_ii (sum_{i<k<=j} R_ik X_kj) on the matrix cores; the accumulator registers of the sum
@@ -584,19 +577,14 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
             __syncthreads();
         }
     }
-    // dense X in place of R (upper triangle + diagonal, zeros below): branch-free products afterwards
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, c = e - i * n;
-        if (i < c) A[i * ld + c] = A[c * ld + i];
-        else if (i == c) A[i * ld + i] = xd[i];
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, c = e - i * n;
-        if (i > c) A[i * ld + c] = 0.0;
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) Rinv[e] = A[(e / n) * ld + e % n];
+    // X(r, c) from that storage (zero below the diagonal): the results are written straight from it -- no pass that
+    // makes X dense in LDS first
+    auto Xe = [&](int r, int c) -> double {
+        if (r >= n || c >= n || r > c) return 0.0;
+        return r == c ? xd[c] : A[c * ld + r];
+    };
+    for (int i = ti; i < n; i += 16)
+        for (int c = tc; c < n; c += 16) Rinv[i * n + c] = Xe(i, c);
     if (Ginv) {
         // G^-1 = X X^T on the matrix cores: tile (ta, tb), tb >= ta, one per wave and turn, mirrored on the way out;
         // X is upper triangular, so the sum over k starts at the column tile (22 k -> 11 k cycles at n = 50, 125 k ->
@@ -609,12 +597,9 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
                 if ((t & 3) != wv) continue;
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 const int ra = 16 * ta + x16, rb = 16 * tb + x16;
-                const double *xa = A + ra * ld, *xb = A + rb * ld;
                 for (int kb = 4 * tb; kb < nkb; ++kb) {
                     const int k = 4 * kb + kq;
-                    const double av = (ra < n && k < n) ? xa[k] : 0.0;
-                    const double bv = (rb < n && k < n) ? xb[k] : 0.0;
-                    acc = mfma16(av, bv, acc);
+                    acc = mfma16(Xe(ra, k), Xe(rb, k), acc);
                 }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
