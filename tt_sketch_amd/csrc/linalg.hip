@@ -622,21 +622,41 @@ __global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__rest
     double *B = sm, *S = sm + n * ld;
     for (int e = tid; e < n * n; e += 256) B[(e / n) * ld + e % n] = Qtop[e];
     __syncthreads();
-    // only the signs are needed: every thread derives the modified pivot itself and the trailing update
-    // uses the unscaled column, so a step is one barrier (it was three plus a one-thread stretch)
+    // only the signs are needed: every thread derives the modified pivots itself and the trailing update uses the
+    // unscaled columns; two columns per barrier as in chol_inv_kernel (row j + 1 after step j through a shadow row)
     const int ti = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < n; ++j) {
+    __shared__ double shadow[2 * 128];
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+        const double *b0 = B + j * ld, *b1 = B + (j + 1) * ld;
+        const double sgn0 = b0[j] >= 0.0 ? -1.0 : 1.0;
+        const double pinv0 = 1.0 / (b0[j] - sgn0);
+        const double g = b1[j] * pinv0;                                  // factor of row j + 1 against row j
+        const double piv1 = fma(-g, b0[j + 1], b1[j + 1]);               // pivot of column j + 1 after step j
+        double sgn1 = piv1 >= 0.0 ? -1.0 : 1.0;
+        if (square && j + 1 == n - 1) sgn1 = -sgn1;
+        const double pinv1 = 1.0 / (piv1 - sgn1);
+        if (tid == 0) { S[j] = sgn0; S[j + 1] = sgn1; }
+        for (int i = j + 2 + ti; i < n; i += 16) {
+            const double f0 = B[i * ld + j] * pinv0;
+            const double f1 = fma(-f0, b0[j + 1], B[i * ld + j + 1]) * pinv1;
+            for (int c = j + 2 + tc; c < n; c += 16) {
+                const double u1 = fma(-g, b0[c], b1[c]);                 // row j + 1 after step j, at c
+                B[i * ld + c] = fma(-f1, u1, fma(-f0, b0[c], B[i * ld + c]));
+            }
+        }
+        double *sh = shadow + ((j >> 1) & 1) * 128;
+        for (int c = j + 2 + tid; c < n; c += 256) sh[c] = fma(-g, b0[c], b1[c]);
+        __syncthreads();
+        for (int c = j + 2 + tid; c < n; c += 256) B[(j + 1) * ld + c] = sh[c];
+    }
+    __syncthreads();
+    if (j < n) {                                                         // odd n: the last pivot
         double sgn = B[j * ld + j] >= 0.0 ? -1.0 : 1.0;
         if (square && j == n - 1) sgn = -sgn;
         if (tid == 0) S[j] = sgn;
-        const double pinv = 1.0 / (B[j * ld + j] - sgn);
-        const double *bj = B + j * ld;
-        for (int i = j + 1 + ti; i < n; i += 16) {
-            const double f = B[i * ld + j] * pinv;
-            for (int c = j + 1 + tc; c < n; c += 16) B[i * ld + c] = fma(-f, bj[c], B[i * ld + c]);
-        }
-        __syncthreads();
     }
+    __syncthreads();
     for (int e = tid; e < n * n; e += 256) Rinv[e] *= S[e % n];
 }
 
