@@ -144,6 +144,14 @@ int ttsk_tt_sketch_sum(int nb, int d, const int64_t *n, const int64_t *s, const 
 int ttsk_chain_step(int nb, int n, int K1, int A, int A2, int J, const double *const *W, int64_t w_c,
                     const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
                     const double *E, double *const *T, double *const *Out, int stream);
+/* The same step (same arguments, same results) on the chunked kernel (csrc/chain_wide.h): the DRM rank A is cut
+ * into chunks dealt over workgroups, a wave carries up to two 16-row tiles.  Covers what ttsk_chain_step does not:
+ * TT ranks K1 beyond 128 and J up to 176 (rank-150 inputs, scripts/plot_timings.py:28-36), input and output DRM
+ * ranks of different tile structure, odd DRM ranks, A2 up to 160, K1 much smaller than A.  TTSK_ERR_UNSUPPORTED
+ * outside that; ttsk_tt_sketch_batch tries ttsk_chain_step's kernel, then this one, then the two-launch form. */
+int ttsk_chain_step_wide(int nb, int n, int K1, int A, int A2, int J, const double *const *W, int64_t w_c,
+                         const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
+                         const double *E, double *const *T, double *const *Out, int stream);
 /* number of doubles ttsk_tt_sketch writes to `out` */
 int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
                             const int64_t *r_lo, const int64_t *r_hi);

@@ -914,6 +914,70 @@ def test_fused_chain_step_against_einsum(tsa, case):
             assert rel(dT[b].get(), want_T[b]) < TOL, (b, rel(dT[b].get(), want_T[b]))
 
 
+def _chain_step_case(entry, case, seed_salt=0):
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, sync
+    nb, n, K1, A, A2, J, right, wt = case
+    rng = np.random.default_rng((hash(case) + seed_salt) % 2**32)
+    W = [rng.standard_normal((K1, A)) for _ in range(nb)]
+    E = rng.standard_normal((A, n, A2))
+    if right:      # X[j][k][c]
+        X = [rng.standard_normal((J, n, K1)) for _ in range(nb)]
+        strides = (n * K1, K1, 1)
+        want_T = [np.einsum("ca,jkc->akj", w, x) for w, x in zip(W, X)]
+    else:          # X[c][k][j]
+        X = [rng.standard_normal((K1, n, J)) for _ in range(nb)]
+        strides = (1, J, n * J)
+        want_T = [np.einsum("ca,ckj->akj", w, x) for w, x in zip(W, X)]
+    want = [np.einsum("akj,akb->jb", t, E) for t in want_T]
+    dW, dX = [DevArray.from_host(w) for w in W], [DevArray.from_host(x) for x in X]
+    dE = DevArray.from_host(E)
+    dO = [DevArray.zeros((J, A2)) for _ in range(nb)]
+    dT = [DevArray.zeros((A, n, J)) for _ in range(nb)] if wt else None
+    P = ctypes.c_void_p
+    arr = lambda xs: (P * nb)(*[x.ptr for x in xs])
+    nat.call(entry, nb, n, K1, A, A2, J, arr(dW), A, arr(dX), strides[0], strides[1], strides[2],
+             X[0].size, P(dE.ptr), arr(dT) if wt else None, arr(dO), 0)
+    sync()
+    for b in range(nb):
+        assert rel(dO[b].get(), want[b]) < TOL, (b, rel(dO[b].get(), want[b]))
+        if wt:
+            assert rel(dT[b].get(), want_T[b]) < TOL, (b, rel(dT[b].get(), want_T[b]))
+
+
+@pytest.mark.parametrize("case", [
+    # (nb, n, K1, A, A2, J, right-chain strides?, T written?) -- the structures ttsk_chain_step does not cover
+    (1, 100, 150, 110, 110, 150, True, False),       # ref150 right chain l=55 x2: K1 > 128, 10 row tiles (3+3+2+2), 2 chunks of 56
+    (1, 100, 150, 55, 55, 150, False, True),         # ref150 left chain: odd ranks (8-byte-aligned E rows), T stored, one chunk
+    (2, 100, 100, 110, 110, 150, True, False),       # first interior step: TT ranks 100 -> 150
+    (1, 100, 150, 58, 58, 100, True, False),         # "+3" right chain, last interior step (J = 100)
+    (4, 40, 150, 145, 108, 150, False, True),        # rank changes structure between the modes; 4 chunks; T stored over chunks
+    (3, 33, 130, 25, 25, 130, False, True),          # small odd rank: strips only in the output? (1 tile + 9 -> 2 tiles)
+    (2, 27, 150, 5, 5, 150, True, False),            # rank 5: output of two strips, chunk of 16 with 5 columns
+    (2, 20, 64, 8, 8, 64, False, True),              # rank 8: two strips
+    (2, 31, 100, 95, 95, 100, True, True),           # odd A2 with the last slice in range: the patched unit
+    (1, 16, 160, 64, 64, 176, True, False),          # 11 row tiles (3+3+3+2), 64-column structure falls back to 48 + 16
+    (2, 50, 100, 160, 160, 100, True, False),        # 10 output tiles, one tile per wave
+    (3, 30, 120, 100, 160, 112, False, True),        # A != A2, 7 waves, chunks of 56 / 48
+    (8, 24, 20, 100, 100, 20, True, False),          # C5 right chain: TT rank 20 against DRM rank 100
+    (8, 24, 20, 50, 50, 20, False, True),            # C5 left chain
+    (2, 9, 37, 33, 47, 29, False, True),             # everything odd
+    (1, 3, 4, 4, 6, 5, True, True),                  # tiny
+])
+def test_wide_chain_step_against_einsum(tsa, case):
+    """ttsk_chain_step_wide (csrc/chain_wide.h): the fused step with the DRM rank cut into chunks over workgroups
+    and up to two row tiles per wave == the two einsums of tensor_train_drm.py:81-87, and the optional T."""
+    _chain_step_case("ttsk_chain_step_wide", case)
+
+
+def test_wide_and_first_fused_kernel_on_shared_shapes(tsa):
+    """Where both kernels apply they sum in different orders (chunks); results agree to rounding."""
+    for case in [(4, 50, 100, 100, 100, 100, True, False), (2, 40, 64, 52, 50, 33, False, True)]:
+        _chain_step_case("ttsk_chain_step", case, 1)
+        _chain_step_case("ttsk_chain_step_wide", case, 1)
+
+
 def test_blocked_sketch_and_rank_increase_match_reference_runs(tsa):
     """(f)3 on the HIP path against runs of the reference itself (tests/golden/blocked_cases.npz, generated by
     tests/golden/make_golden_blocked.py): `blocked_stream_sketch` (sketch.py:493-525) over DRM rank slices and

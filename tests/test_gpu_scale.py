@@ -75,6 +75,52 @@ def test_c3_full_size_vs_oracle(tsa):
     _check(stt.sketch_, *orc.general_sketch("tt", cores, ld, rd, "streaming"))
 
 
+@pytest.mark.parametrize("l,r", [(55, 110), (55, 58), (145, 290), (25, 50), (5, 10), (95, 98)])
+def test_ref150_published_shape_vs_oracle(tsa, l, r):
+    """The reference's own timing benchmark (scripts/plot_timings.py:28-36,94-124): shape 100^5, TT-rank 150 (trimmed
+    to (100, 150, 150, 100)), left rank l (trimmed), right rank r = 2 l or l + 3 (not trimmed, sketch.py:188-209).
+    TT ranks beyond 128, odd DRM ranks, DRM ranks that change between modes: the chunked fused chain step
+    (csrc/chain_wide.h) and the chunked Psi product where they apply, the two-launch kernels elsewhere."""
+    from tt_sketch_amd.utils import process_tt_rank
+    rng = np.random.default_rng(150 + l)
+    shape = (100,) * 5
+    cores = orc.random_tt(shape, (100, 150, 150, 100), rng)
+    lrank = process_tt_rank(l, shape, trim=True)
+    ld, rd = orc.random_tt_drm(shape, lrank, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left = tsa.TensorTrainDRM(lrank, shape, False, seed=1, cores=ld.cores)
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=rd.cores)
+    stt = tsa.stream_sketch(tsa.TensorTrain(cores), lrank, (r,) * 4, left_drm=left, right_drm=right)
+    _check(stt.sketch_, *orc.general_sketch("tt", cores, ld, rd, "streaming"))
+
+
+def test_ref150_batched_pass_vs_oracle(tsa):
+    """Four rank-150 TTs through one batched pass (ttsk_tt_sketch_batch) at l=55 / r=110: every tensor against the oracle."""
+    import ctypes
+    from tt_sketch_amd.device import DevArray, sync
+    from tt_sketch_amd.tt_fused import TTSketchPlan
+    rng = np.random.default_rng(151)
+    shape, tt_rank, B = (100,) * 5, (100, 150, 150, 100), 4
+    tts = [orc.random_tt(shape, tt_rank, rng) for _ in range(B)]
+    ld, rd = orc.random_tt_drm(shape, (55,) * 4, False, rng), orc.random_tt_drm(shape, 110, True, rng)
+    left = tsa.TensorTrainDRM(55, shape, False, seed=1, cores=ld.cores)
+    right = tsa.TensorTrainDRM(110, shape, True, seed=2, cores=rd.cores)
+    plan = TTSketchPlan(shape, tt_rank, left, right)
+    stride = plan.size + (plan.size & 1)
+    out = DevArray.empty((B * stride,))
+    keep, flat = [], []
+    for t in tts:
+        p1, k1 = plan.core_pointers(tsa.TensorTrain(t))
+        keep.append(k1)
+        flat += [p1[i] for i in range(plan.d)]
+    plan.run_batch((ctypes.c_void_p * len(flat))(*flat), B, out, stride)
+    sync()
+    got = out.get()
+    for b in range(B):
+        oP, oO = orc.general_sketch("tt", tts[b], ld, rd, "streaming")
+        want = np.concatenate([a.ravel() for a in oP + oO])
+        assert rel(got[b * stride:b * stride + plan.size], want) < TOL, b
+
+
 def test_c4_sparse_scaled_and_full_size_properties(tsa):
     """configs[3]: FROSTT-style COO d=5 shape (200,150,100,120,300), SparseGaussianDRM l=10 r=15.
     nnz=2e5 against the oracle; nnz=4e6 through linearity over nnz shards and a Psi checksum."""

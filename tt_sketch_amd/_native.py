@@ -62,6 +62,8 @@ def _bind(lib):
         "ttsk_tt_sketch_sum": [I, I] + [POINTER(c_int64)] * 8 + [POINTER(P)] * 3 + [P, I, I],
         "ttsk_chain_step": [I, I, I, I, I, I, POINTER(P), c_int64, POINTER(P), c_int64, c_int64, c_int64, c_int64, P,
                             POINTER(P), POINTER(P), I],
+        "ttsk_chain_step_wide": [I, I, I, I, I, I, POINTER(P), c_int64, POINTER(P), c_int64, c_int64, c_int64, c_int64, P,
+                                 POINTER(P), POINTER(P), I],
         "ttsk_prof_enable": [I],
         "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
@@ -136,7 +138,7 @@ _dirty = set()
 # entry points whose LAST argument is the library stream their work is queued on
 _STREAM_LAST = frozenset((
     "ttsk_memset", "ttsk_d2d", "ttsk_gemm", "ttsk_copy_strided", "ttsk_axpby", "ttsk_sum_slices",
-    "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
+    "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_chain_step_wide", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
     "ttsk_fill_normal", "ttsk_fill_normal_many", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
     "ttsk_sparse_sort_mode", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
     "ttsk_qr_thin", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))

@@ -53,6 +53,8 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c)
 bool prof_on();
 void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, bool bk);
 void prof_close(hipStream_t st);
+enum { PROF_SAMPLER = 6, PROF_SPARSE = 7, PROF_SOLVE = 8 };
+void prof_open_named(hipStream_t st, int cls, double work, const char *name);   // work in the class's own unit
 
 // svd_grid.hip: one-sided Jacobi SVD over all compute units (n beyond the one-workgroup kernel)
 int svd_jacobi_grid(const double *A, int64_t m, int64_t n, double *US, double *S, double *Vt, int stream, hipStream_t st);

@@ -1,6 +1,7 @@
 // Psi_mu = T_mu R_mu (tensor_train_sketch.py:28-34) as a streamed x small product in the style of
 // chain_fused.h:
-//   C[j][a] (+)= sum_c S[j][c] W[c][a]       j ~ 10^4 rows streamed once, K1, A <= 128
+//   C[j][a] (+)= sum_c S[j][c] W[c][a]       j ~ 10^4 rows streamed once; K1 as the LDS allows (rank-150 TTs),
+//                                            A beyond 112 in column chunks dealt over workgroups
 // W sits in LDS in the pair-interleaved image of chain_fused.h (conflict-free fragment reads), every one of
 // the 8 waves of a workgroup walks its own 16-row tiles of S: fragments straight from memory through a
 // register ring, the W fragments of the next k-block requested before this one's matrix instructions,
@@ -17,7 +18,8 @@ struct StreamSmall {
     const double *S[SK_MAXB];
     const double *W[SK_MAXB];
     double *C[SK_MAXB];
-    int nb, wpp;                 // problems, workgroups per problem
+    int nb, wpp;                 // problems, row-tile groups per problem
+    int nac, ac;                 // column chunks of A (one workgroup each: disjoint outputs), columns per chunk
     int J, K1, A;
     int64_t s_j, w_c, c_j;       // row strides (elements): S rows, W rows, C rows; columns contiguous
     int64_t s_extent, c_extent;
@@ -33,7 +35,9 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
     double *Wl = ss_lds;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int x16 = lane & 15, kq = lane >> 4;
-    const int prob = blockIdx.x / a.wpp, g = blockIdx.x - prob * a.wpp;
+    const int prob = blockIdx.x / (a.wpp * a.nac), unit = blockIdx.x - prob * (a.wpp * a.nac);
+    const int g = unit / a.nac, a0 = (unit - g * a.nac) * a.ac;
+    const int cnt = a.A - a0 < a.ac ? a.A - a0 : a.ac;       // columns of this chunk
     const int KB1 = ((a.K1 + 3) / 4 + UNR - 1) / UNR * UNR, AP = a.AP;      // padded to whole runs: zero rows of the W image
     {
         const double *Wp = uniform_ptr(a.W[prob]);
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
             for (int u = 0; u < BATCH; ++u) {
                 const int e = e0 + 512 * u;
                 const int c = e / AP, col = e - c * AP;
-                v[u] = ld8(rw, (e < total && c < a.K1 && col < a.A) ? (uint32_t)(((int64_t)c * a.w_c + col) * 8) : OOB_OFF, 0);
+                v[u] = ld8(rw, (e < total && c < a.K1 && col < cnt) ? (uint32_t)(((int64_t)c * a.w_c + a0 + col) * 8) : OOB_OFF, 0);
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
@@ -120,10 +124,10 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = j0 + 4 * t + kq;
-            const uint32_t ro = (uint32_t)(((int64_t)j * a.c_j + x16) * 8);
+            const uint32_t ro = (uint32_t)(((int64_t)j * a.c_j + a0 + x16) * 8);
 #pragma unroll
             for (int p = 0; p < NF; ++p) {
-                const uint32_t off = (j < a.J && 16 * p + x16 < a.A) ? ro + 128u * p : OOB_OFF;
+                const uint32_t off = (j < a.J && 16 * p + x16 < cnt) ? ro + 128u * p : OOB_OFF;
                 double v = acc[p][t];
                 if (a.accumulate) v += ld8(rc, off, 0);
                 st8(rc, off, v);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512) void stream_small_kernel(StreamSmall a)
         for (int q = 0; q < STR; ++q) {
             // 4x4x4 result: lane (i = l >> 4, beta = (l >> 2) & 3, c = l & 3) holds row 4 beta + i, column c of the strip
             const int j = j0 + 4 * ((lane >> 2) & 3) + kq, col = 16 * NF + 4 * q + (lane & 3);
-            const uint32_t off = (j < a.J && col < a.A) ? (uint32_t)(((int64_t)j * a.c_j + col) * 8) : OOB_OFF;
+            const uint32_t off = (j < a.J && col < cnt) ? (uint32_t)(((int64_t)j * a.c_j + a0 + col) * 8) : OOB_OFF;
             double v = accs[q];
             if (a.accumulate) v += ld8(rc, off, 0);
             st8(rc, off, v);

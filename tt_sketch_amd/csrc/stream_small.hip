@@ -45,28 +45,36 @@ int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st)
     (void)stream;
     static int on = [] { const char *e = getenv("TTSK_STREAM_SMALL"); return e ? atoi(e) : 1; }();
     if (!on || c.nb < 1 || c.nb > SK_MAXB) return 0;
-    if (c.K1 < 1 || c.K1 > 128 || c.A < 4 || c.A > 112 || c.J < 1024) return 0;
+    if (c.K1 < 1 || c.A < 4 || c.J < 1024) return 0;
     if (c.s_j < c.K1 || c.w_c < c.A || c.c_j < c.A) return 0;
-    int nf = c.A / 16, str;
-    const int rem = c.A % 16;
-    if (rem == 0) str = 0;
-    else if (rem <= 4) str = 1;
-    else if (rem <= 8) str = 2;
-    else { nf += 1; str = 0; }
-    if (nf < 1 || nf + (str ? 1 : 0) > 7) return 0;
-    StreamSmall a{};
-    a.nb = c.nb; a.J = c.J; a.K1 = c.K1; a.A = c.A;
-    a.s_j = c.s_j; a.w_c = c.w_c; a.c_j = c.c_j;
-    a.accumulate = c.accumulate;
-    a.AP = 16 * nf + 4 * str;
     const int kb = (c.K1 + 3) / 4;
     const int pad25 = (kb + 24) / 25 * 25, pad5 = (kb + 4) / 5 * 5;
     const int unr = pad25 <= pad5 + 1 ? 25 : 5;         // straight-line runs of k-blocks (padded to whole runs)
     const int KB1 = unr == 25 ? pad25 : pad5;
-    const size_t lds = (size_t)4 * (KB1 + 1) * a.AP * 8;
-    if (lds > 160 * 1024) return 0;
+    // column chunks: the fewest whose W image fits the LDS and whose structure (<= 7 tiles) is instantiated
+    int nac = 0, nf = 0, str = 0, need = 0;
+    size_t lds = 0;
+    for (int t = 1; t <= 16 && !nac; ++t) {
+        need = (int)((cdiv(c.A, t) + 3) / 4 * 4);
+        nf = need / 16;
+        const int rem = need % 16;
+        if (rem == 0) str = 0;
+        else if (rem <= 4) str = 1;
+        else if (rem <= 8) str = 2;
+        else { nf += 1; str = 0; }
+        if (nf < 1 || nf + (str ? 1 : 0) > 7) continue;
+        lds = (size_t)4 * (KB1 + 1) * (16 * nf + 4 * str) * 8;
+        if (lds <= 160 * 1024) nac = t;
+    }
+    if (!nac) return 0;
+    StreamSmall a{};
+    a.nb = c.nb; a.J = c.J; a.K1 = c.K1; a.A = c.A;
+    a.nac = nac; a.ac = nac == 1 ? c.A : need;
+    a.s_j = c.s_j; a.w_c = c.w_c; a.c_j = c.c_j;
+    a.accumulate = c.accumulate;
+    a.AP = 16 * nf + 4 * str;
     const int ntiles = (c.J + 15) / 16;
-    int wpp = ss_num_cu() / c.nb > 0 ? ss_num_cu() / c.nb : 1;
+    int wpp = ss_num_cu() / (c.nb * nac) > 0 ? ss_num_cu() / (c.nb * nac) : 1;
     if (wpp > (ntiles + 7) / 8) wpp = (ntiles + 7) / 8;
     a.wpp = wpp;
     a.s_extent = (int64_t)(c.J - 1) * c.s_j + c.K1;
@@ -80,7 +88,7 @@ int stream_small_try(const StreamSmallArgs &c, int stream, hipStream_t st)
     }
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * c.nb * (double)c.J * c.K1 * c.A, 7, nf * 10 + str, unr == 25, false);
-    const int rc = launch_ss(a, nf, str, unr, lds, c.nb * wpp, st);
+    const int rc = launch_ss(a, nf, str, unr, lds, c.nb * wpp * nac, st);
     if (prof) prof_close(st);
     return rc == TTSK_OK ? 1 : (rc == 1 ? 0 : rc);
 }

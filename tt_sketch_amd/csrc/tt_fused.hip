@@ -5,12 +5,13 @@
 #include "common.h"
 #include "skinny.h"
 #include "chain_fused.h"
+#include "chain_wide.h"
 #include "stream_small.h"
 
 namespace ttsk {
 
 constexpr int SMAX_ROWS = 112;   // rows a fused step addresses in an X slab (tt_step.hip SMAX)
-constexpr int NCLS = 8;
+constexpr int NCLS = 12;      // 0-5 TT pipeline classes, 6 samplers, 7 sparse Psi / Omega, 8 small factorisations, 9-10 free, 11 everything else
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 static char g_kname[NCLS][96];
 static double g_kname_flops[NCLS];   // the name kept per class is that of its largest launch
@@ -54,6 +55,25 @@ void prof_open(hipStream_t st, double flops, int family, int tiles, bool ak, boo
     g_recs.push_back(r);
 }
 void prof_close(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+
+// brackets for kernels outside ttsk_gemm (samplers, sparse segmented sums, factorisations): class and name given
+// by the caller, `work` in the class's own unit (samples, bytes, flops)
+void prof_open_named(hipStream_t st, int cls, double work, const char *name)
+{
+    if (cls == -2) cls = g_cls;                   // the class the TT driver has set for this product
+    if (cls < 0 || cls >= NCLS) cls = NCLS - 1;
+    if (work >= g_kname_flops[cls]) {
+        g_kname_flops[cls] = work;
+        snprintf(g_kname[cls], sizeof(g_kname[0]), "%s", name);
+    }
+    ProfRec r{};
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, st);
+    r.cls = cls;
+    r.flops = work;
+    g_recs.push_back(r);
+}
 
 static void prof_flush()
 {
@@ -316,7 +336,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             ChainStepArgs cs{nb, (int)nn, (int)sp, (int)rho, (int)rhop, (int)sn, Wp, rho, Xp, nn * sp, sp, 1, sn * nn * sp,
                              DR[j], nullptr, Op};
             g_cls = 1;
-            const int fz = (sp <= 128 && sn <= 128 && rho <= 128 && rhop <= 128) ? chain_fused_try(cs, stream, st) : 0;
+            int fz = (sp <= 128 && sn <= 128 && rho <= 128 && rhop <= 128) ? chain_fused_try(cs, stream, st) : 0;
+            if (fz == 0) fz = chain_wide_try(cs, stream, st);
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
             if (fz == 1) return TTSK_OK;
@@ -374,7 +395,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             ChainStepArgs cs{nb, (int)nn, (int)sn, (int)lfull, (int)lt[mu + 1], (int)sp, Wp, lfull, Xp, 1, sp, nn * sp,
                              sn * nn * sp, DL[mu], Tp, Op};
             g_cls = 3;
-            const int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
+            int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
+            if (fz == 0) fz = chain_wide_try(cs, aux, st_aux);
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
             if (fz == 1) return TTSK_OK;
