@@ -447,6 +447,11 @@ int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int
     // multipliers (fast_lazy_gaussian.pyx:60-71), i.e. when the flat index really is < prod(shape).
     static const int dedupe = [] { const char *e = getenv("TTSK_SPARSE_DEDUPE"); return e ? atoi(e) : 1; }();
     const int w = rank_max - rank_min;
+    struct ProfScope {      // device time of the whole sampling pass (work unit: Gaussian samples delivered)
+        hipStream_t st; bool on;
+        ProfScope(hipStream_t s, double samples) : st(s), on(prof_on()) { if (on) prof_open_named(st, PROF_SAMPLER, samples, "sample_rows_kernel / expand_rows_kernel"); }
+        ~ProfScope() { if (on) prof_close(st); }
+    } prof_scope(st, (double)tot);
     double prod = 1.0;
     for (int i = 0; i < m; ++i) prod *= (double)shape[i];
     if (dedupe && w <= 32 && prod * 4.0 <= (double)N && prod < 16777216.0) {

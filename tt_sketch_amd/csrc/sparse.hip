@@ -371,6 +371,11 @@ int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int
     TTSK_ARG(l >= 1 && r >= 1 && n >= 1, "ttsk_sparse_psi: bad shape");
     TTSK_ARG(dev_idx_row || n == 1, "ttsk_sparse_psi: a NULL index row means a single slice (n = 1)");
     if (N == 0) return TTSK_OK;
+    struct ProfScope {      // device time of the segmented sum (work unit: algorithmic bytes = panels + values + indices)
+        hipStream_t st; bool on;
+        ProfScope(hipStream_t s, double bytes) : st(s), on(prof_on()) { if (on) prof_open_named(st, PROF_SPARSE, bytes, "sparse_psi_mfma_kernel"); }
+        ~ProfScope() { if (on) prof_close(st); }
+    } prof_scope(st, 8.0 * (double)N * (double)((dev_Lv ? l : 0) + (dev_Rv ? r : 0) + 1 + (dev_idx_row ? 1 : 0) + (dev_perm ? 1 : 0)));
     // MFMA kernel: small ranks, and either one slice or mode-sorted input with long slices
     static int mfma_on = [] { const char *e = getenv("TTSK_SPARSE_MFMA"); return e ? atoi(e) : 1; }();
     const bool single = dev_idx_row == nullptr || n == 1;

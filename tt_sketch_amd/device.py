@@ -87,6 +87,21 @@ def _pool_give(size: int, ptr: int) -> None:
         nat.lib().ttsk_free(ctypes.c_void_p(old))
 
 
+def release_cached(min_bytes: int = _POOL_MIN) -> int:
+    """hipFree every pooled buffer of at least ``min_bytes`` (after a device-wide sync); returns the bytes
+    released.  For callers that move between working sets of very different sizes (bench.py's sub-records)."""
+    import gc
+    gc.collect()
+    nat.call("ttsk_sync", -1)
+    freed = 0
+    for size in [k for k in _pool if k >= min_bytes]:
+        for _, ptr in _pool.pop(size):
+            nat.lib().ttsk_free(ctypes.c_void_p(ptr))
+            _pool_bytes[size >= _POOL_MIN] -= size
+            freed += size
+    return freed
+
+
 class _Buffer:
     """Owns one ttsk_malloc allocation (recycled through the pool above)."""
     __slots__ = ("ptr", "nbytes", "_pooled")
