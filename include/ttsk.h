@@ -256,6 +256,18 @@ int ttsk_triu(double *dev_A, int64_t m, int64_t n, int stream);
  * A (m, n) row-major with m >= n is overwritten by Q (m, n); Householder with LAPACK's
  * sign convention.  R is not returned (the reference discards it). */
 int ttsk_qr_thin(double *dev_A, int64_t m, int64_t n, int stream);
+/* orth_step (sketch_dispatch.py:160-174) as ONE call with no read-back: Q (m, k) = qr_thin(Psi_mat pinv(Omega)), k = l,
+ * Psi_mat (m, r2) row-major, Omega (l, r2) -- or Omega == NULL: Q = qr_thin(Psi_mat), k = r2 (hmt_sketch).  Same Q as
+ * ttsk_pinv + product + ttsk_qr_thin on their fast paths (normal equations, CholeskyQR2, LAPACK's column signs) for
+ * ranks up to 256.  The acceptance tests of those factorisations are NOT waited for: a rejection (Omega rank deficient
+ * or kappa > 300, Psi_mat Omega^+ with kappa > 1e6) sets the stream's deferred flag and leaves Q meaningless; the caller
+ * reads the flag once when the whole sketch is queued (ttsk_deferred_status) and then repeats it through ttsk_pinv /
+ * ttsk_qr_thin.  TTSK_ERR_UNSUPPORTED outside the fast path (ranks > 256, TTSK_FAST_SOLVES=0). */
+int ttsk_orth_step(const double *dev_psi, int64_t m, int64_t r2, const double *dev_omega, int64_t l, double *dev_q,
+                   int stream);
+/* *host_flag = 1 if a factorisation queued by ttsk_orth_step on `stream` was rejected since the last call; waits for
+ * the stream and clears the flag. */
+int ttsk_deferred_status(int stream, int *host_flag);
 
 /* ---- multi-GPU: one RCCL sum of the packed partial sketch ------------------
  * SketchContainer.__add__ across ranks (sketch_container.py:61-69). */

@@ -914,6 +914,68 @@ def test_fused_chain_step_against_einsum(tsa, case):
             assert rel(dT[b].get(), want_T[b]) < TOL, (b, rel(dT[b].get(), want_T[b]))
 
 
+@pytest.mark.parametrize("shape", [(2000, 100, 50), (3000, 60, None), (4000, 290, 145), (2500, 148, 145), (1800, 200, None),
+                                   (300, 256, 256), (700, 130, 129)])
+def test_orth_step_one_call_and_ranks_beyond_128(tsa, shape):
+    """ttsk_orth_step (sketch_dispatch.py:160-174 in one call, verdicts deferred) == scipy lstsq + qr incl. LAPACK's
+    column signs; ranks 129..256 through the 2 x 2 block Cholesky (rank 145 / 290 of scripts/plot_timings.py)."""
+    import ctypes
+    import scipy.linalg
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    m, r2, l = shape
+    rng = np.random.default_rng(m + r2)
+    Psi = rng.standard_normal((m, r2))
+    Om = None if l is None else rng.standard_normal((l, r2))
+    k = r2 if l is None else l
+    dP = DevArray.from_host(Psi)
+    dO = None if Om is None else DevArray.from_host(Om)
+    dQ = DevArray.empty((m, k))
+    P = ctypes.c_void_p
+    nat.call("ttsk_orth_step", P(dP.ptr), m, r2, None if dO is None else P(dO.ptr), k, P(dQ.ptr), 0)
+    flag = ctypes.c_int(7)
+    nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+    assert flag.value == 0
+    M = Psi if Om is None else orc.right_mul_pinv(Psi, Om)
+    want, _ = scipy.linalg.qr(M, mode="economic")
+    got = dQ.get()
+    assert np.linalg.norm(got.T @ got - np.eye(k)) < 1e-12
+    assert rel(got, want) < 1e-10            # same Q as dgeqrf / dorgqr, signs included
+    # the stand-alone entry points at the same sizes (pinv beyond 128 columns, QR beyond 128 columns)
+    A = M.copy()
+    dA = DevArray.from_host(A)
+    nat.call("ttsk_qr_thin", P(dA.ptr), m, k, 0)
+    assert rel(dA.get(), want) < 1e-10
+    if Om is not None:
+        from tt_sketch_amd.utils import right_mul_pinv
+        assert rel(right_mul_pinv(Psi[:64], Om), orc.right_mul_pinv(Psi[:64], Om)) < 1e-10
+
+
+def test_orth_step_deferred_flag_on_rank_deficient_input(tsa):
+    """A rank-deficient Omega (or unfolding) must set the deferred flag -- and only then; the flag clears on read."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    rng = np.random.default_rng(9)
+    P = ctypes.c_void_p
+    m, r2, l = 1500, 80, 40
+    Psi = rng.standard_normal((m, r2))
+    Om_bad = rng.standard_normal((l, 10)) @ rng.standard_normal((10, r2))
+    dP, dO, dQ = DevArray.from_host(Psi), DevArray.from_host(Om_bad), DevArray.empty((m, l))
+    flag = ctypes.c_int(0)
+    nat.call("ttsk_orth_step", P(dP.ptr), m, r2, P(dO.ptr), l, P(dQ.ptr), 0)
+    nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+    assert flag.value == 1
+    nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+    assert flag.value == 0
+    Psi_bad = rng.standard_normal((m, 7)) @ rng.standard_normal((7, r2))          # hmt: unfolding of rank 7
+    dP = DevArray.from_host(Psi_bad)
+    dQ = DevArray.empty((m, r2))
+    nat.call("ttsk_orth_step", P(dP.ptr), m, r2, None, r2, P(dQ.ptr), 0)
+    nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+    assert flag.value == 1
+
+
 def _chain_step_case(entry, case, seed_salt=0):
     import ctypes
     from tt_sketch_amd import _native as nat

@@ -13,6 +13,8 @@
 
 namespace ttsk {
 
+constexpr int CHOL_MAX_N = 256;
+
 // sum over the 16 lanes of a DPP row, result in every lane: x += ror(x, 8), 4, 2, 1 (v_mov_dpp row_ror)
 template <int CTRL>
 __device__ __forceinline__ double jac_dpp(double v)
@@ -461,9 +463,11 @@ namespace ttsk {
 
 // G (n x n symmetric, row-major) = R^T R; Rinv = R^-1 (upper triangular, dense n x n) and optionally
 // Ginv = Rinv Rinv^T = G^-1.  status[0] = 0 ok, 1 rejected.
+// sticky (optional): set to 1 on rejection, never cleared here (deferred verdicts: ttsk_orth_step);
+// pminmax (optional): smallest / largest pivot, for callers that combine several blocks (chol_inv_any).
 __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
                                                        double *__restrict__ Ginv, int *__restrict__ status,
-                                                       double cond_tol)
+                                                       double cond_tol, int *__restrict__ sticky, double *__restrict__ pminmax)
 {
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
@@ -515,7 +519,12 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         pmin = fmin(pmin, piv);
         pmax = fmax(pmax, piv);
     }
-    if (tid == 0) status[0] = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
+    if (tid == 0) {
+        const int rej = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
+        status[0] = rej;
+        if (rej && sticky) *sticky = 1;
+        if (pminmax) { pminmax[0] = bad ? -1.0 : pmin; pminmax[1] = pmax; }
+    }
     // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
     if (tid < n) xd[tid] = 1.0 / sqrt(A[tid * ld + tid] > 0.0 ? A[tid * ld + tid] : 1.0);
     __syncthreads();
@@ -660,6 +669,29 @@ __global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__rest
     for (int e = tid; e < n * n; e += 256) Rinv[e] *= S[e % n];
 }
 
+// The same signs for n beyond one workgroup's LDS (129..256): the working copy is B itself in global memory (L2), one
+// column per step, 1024 threads.  Only the signs are needed, so the trailing update uses the unscaled columns.
+__global__ __launch_bounds__(1024) void hh_sign_scale_global_kernel(double *__restrict__ B, int n, int square, double *__restrict__ Rinv)
+{
+    __shared__ double S[CHOL_MAX_N];
+    const int tid = threadIdx.x;
+    for (int j = 0; j < n; ++j) {
+        const double piv = B[j * n + j];
+        double sgn = piv >= 0.0 ? -1.0 : 1.0;
+        if (square && j == n - 1) sgn = -sgn;
+        if (tid == 0) S[j] = sgn;
+        const double pinv = 1.0 / (piv - sgn);
+        const int rem = n - j - 1;
+        for (int e = tid; e < rem * rem; e += 1024) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            B[i * n + c] = fma(-B[i * n + j] * pinv, B[j * n + c], B[i * n + c]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 1024) Rinv[e] *= S[e % n];
+}
+
 static int small_gemm(int64_t M, int64_t N, int64_t K, const double *A, int64_t a_m, int64_t a_k, const double *B,
                       int64_t b_k, int64_t b_n, double *C, int stream)
 {
@@ -670,7 +702,8 @@ static int small_gemm(int64_t M, int64_t N, int64_t K, const double *A, int64_t 
     return ttsk_gemm(&d, A, B, C, nullptr, stream);
 }
 
-static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st)
+static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st,
+                       int *sticky = nullptr, double *pminmax = nullptr)
 {
     static bool attr = false;
     if (!attr) {
@@ -678,8 +711,62 @@ static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *
         TTSK_HIP(hipFuncSetAttribute((const void *)hh_sign_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status, cond_tol);
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status, cond_tol,
+                       sticky, pminmax);
     TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+static int gemm_ex(int64_t M, int64_t N, int64_t K, const double *A, int64_t a_m, int64_t a_k, const double *B, int64_t b_k,
+                   int64_t b_n, double *C, int64_t c_m, double alpha, int accumulate, int stream)
+{
+    ttsk_gemm_desc d{};
+    d.batch = 1; d.M = M; d.N = N; d.Ko = 1; d.Ki = K;
+    d.a_m = a_m; d.a_ki = a_k; d.b_ki = b_k; d.b_n = b_n; d.c_m = c_m; d.c_n = 1;
+    d.alpha = alpha; d.accumulate = accumulate;
+    return ttsk_gemm(&d, A, B, C, nullptr, stream);
+}
+
+// verdict of a two-block factorisation: both blocks accepted AND the pivots of the whole matrix within cond_tol
+__global__ void chol_combine_kernel(const double *pm, const int *st2, double cond_tol, int *status, int *sticky)
+{
+    const double lo = fmin(pm[0], pm[2]), hi = fmax(pm[1], pm[3]);
+    const int rej = (st2[0] || st2[1] || !(lo > 0.0) || lo < cond_tol * cond_tol * hi) ? 1 : 0;
+    status[0] = rej;
+    if (rej && sticky) *sticky = 1;
+}
+
+// The same contract as chol_inv_kernel for n up to 256: beyond 128 (the one-workgroup kernel's LDS) a 2 x 2 block
+// factorisation -- R11 = chol(G11), R12 = R11^-T G12, R22 = chol(G22 - R12^T R12), R^-1 = [X11, -X11 R12 X22; 0, X22] --
+// i.e. two one-workgroup factorisations and a handful of small products (rank 145 / 290 of scripts/plot_timings.py).
+// ws: chol_ws_elems(n) doubles from the caller's arena (nested scratch() calls would move it).
+constexpr int CHOL_ONE = 128, CHOL_MAX = 256;
+static size_t chol_ws_elems(int n) { return n <= CHOL_ONE ? 0 : (size_t)6 * CHOL_ONE * CHOL_ONE + 16; }
+
+static int chol_inv_any(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, int stream,
+                        hipStream_t st, double *ws, int *sticky = nullptr)
+{
+    if (n <= CHOL_ONE) return launch_chol(G, n, Rinv, Ginv, status, cond_tol, st, sticky);
+    if (n > CHOL_MAX || !ws) return TTSK_ERR_UNSUPPORTED;
+    const int n1 = ((n + 1) / 2 + 15) & ~15, n2 = n - n1;
+    double *G11 = ws, *X11 = G11 + (size_t)n1 * n1, *R12 = X11 + (size_t)n1 * n1, *S = R12 + (size_t)n1 * n2;
+    double *X22 = S + (size_t)n2 * n2, *Y = X22 + (size_t)n2 * n2, *pm = Y + (size_t)n1 * n2;
+    int *st2 = (int *)(pm + 4);
+    int rc;
+    TTSK_HIP(hipMemcpy2DAsync(G11, (size_t)n1 * 8, G, (size_t)n * 8, (size_t)n1 * 8, n1, hipMemcpyDeviceToDevice, st));
+    if ((rc = launch_chol(G11, n1, X11, nullptr, st2, 0.0, st, nullptr, pm))) return rc;
+    if ((rc = gemm_ex(n1, n2, n1, X11, 1, n1, G + n1, n, 1, R12, n2, 1.0, 0, stream))) return rc;           // R12 = X11^T G12
+    TTSK_HIP(hipMemcpy2DAsync(S, (size_t)n2 * 8, G + (size_t)n1 * n + n1, (size_t)n * 8, (size_t)n2 * 8, n2, hipMemcpyDeviceToDevice, st));
+    if ((rc = gemm_ex(n2, n2, n1, R12, 1, n2, R12, n2, 1, S, n2, -1.0, 1, stream))) return rc;               // S = G22 - R12^T R12
+    if ((rc = launch_chol(S, n2, X22, nullptr, st2 + 1, 0.0, st, nullptr, pm + 2))) return rc;
+    hipLaunchKernelGGL(chol_combine_kernel, dim3(1), dim3(1), 0, st, pm, st2, cond_tol, status, sticky);
+    TTSK_LAUNCH_CHECK();
+    if ((rc = gemm_ex(n1, n2, n2, R12, n2, 1, X22, n2, 1, Y, n2, 1.0, 0, stream))) return rc;                 // Y = R12 X22
+    TTSK_HIP(hipMemsetAsync(Rinv, 0, (size_t)n * n * 8, st));
+    TTSK_HIP(hipMemcpy2DAsync(Rinv, (size_t)n * 8, X11, (size_t)n1 * 8, (size_t)n1 * 8, n1, hipMemcpyDeviceToDevice, st));
+    TTSK_HIP(hipMemcpy2DAsync(Rinv + (size_t)n1 * n + n1, (size_t)n * 8, X22, (size_t)n2 * 8, (size_t)n2 * 8, n2, hipMemcpyDeviceToDevice, st));
+    if ((rc = gemm_ex(n1, n2, n1, X11, n1, 1, Y, n2, 1, Rinv + n1, n, -1.0, 0, stream))) return rc;           // X12 = -X11 Y
+    if (Ginv && (rc = gemm_ex(n, n, n, Rinv, n, 1, Rinv, 1, n, Ginv, n, 1.0, 0, stream))) return rc;          // G^-1 = X X^T
     return TTSK_OK;
 }
 
@@ -715,25 +802,45 @@ static int *pinv_dev_status(int stream)
     return p ? p + stream : nullptr;
 }
 
-// 1 = attempt queued, 0 = not applicable, < 0 = error
-static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st)
+// deferred verdicts (ttsk_orth_step): one sticky word per stream, set by any rejected fast-path factorisation since the
+// last ttsk_deferred_status
+static int *deferred_flag(int stream)
+{
+    static int *p = [] {
+        int *q = nullptr;
+        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) return (int *)nullptr;
+        if (hipMemset(q, 0, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) return (int *)nullptr;
+        return q;
+    }();
+    return p ? p + stream : nullptr;
+}
+
+static size_t pinv_ws_elems(int n) { return (size_t)3 * n * n + 16 + chol_ws_elems(n); }
+
+// 1 = attempt queued, 0 = not applicable, < 0 = error.  ws_in: pinv_ws_elems(n) doubles of the caller's, or nullptr
+// (then from the stream's arena).  sticky: deferred mode -- no copy of the verdict to the host, the rejection is
+// recorded in *sticky and the caller decides at the end.
+static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st,
+                               double *ws_in = nullptr, int *sticky = nullptr)
 {
     const int n = (int)(l <= r ? l : r);
     int *hs = pinv_host_status();
     int *status = pinv_dev_status(stream);
-    if (n > 128 || !hs || !status) return 0;
-    double *ws = (double *)scratch(stream, SCRATCH_MISC, (size_t)(3 * n * n + 16) * 8);
+    if (n > CHOL_MAX || !hs || !status) return 0;
+    double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, pinv_ws_elems(n) * 8);
     if (!ws) return TTSK_ERR_HIP;
-    double *G = ws, *Rinv = ws + n * n, *Ginv = ws + 2 * n * n;
+    double *G = ws, *Rinv = ws + n * n, *Ginv = ws + 2 * n * n, *cws = ws + 3 * n * n + 16;
     int rc;
     if (l <= r) rc = small_gemm(l, l, r, omega, r, 1, omega, 1, r, G, stream);          // Omega Omega^T
     else        rc = small_gemm(r, r, l, omega, 1, r, omega, r, 1, G, stream);          // Omega^T Omega
     if (rc) return rc;
     // normal equations square the condition number: accept kappa(Omega) up to ~300 (error ~1e-11)
-    rc = launch_chol(G, n, Rinv, Ginv, status, 1.0 / 300.0, st);
+    rc = chol_inv_any(G, n, Rinv, Ginv, status, 1.0 / 300.0, stream, st, n > CHOL_ONE ? cws : nullptr, sticky);
     if (rc) return rc;
-    hs[stream] = 1;
-    TTSK_HIP(hipMemcpyAsync(hs + stream, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!sticky) {
+        hs[stream] = 1;
+        TTSK_HIP(hipMemcpyAsync(hs + stream, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // Omega^T G^-1
     else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // G^-1 Omega^T
     return rc ? rc : 1;
@@ -749,29 +856,40 @@ static int pinv_cholesky_verdict(int64_t l, int64_t r, int stream, hipStream_t s
     return host_status ? 0 : 1;
 }
 
-// thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected
-static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st)
+static size_t qr_ws_elems(int64_t m, int n) { return (size_t)m * n + 4 * (size_t)n * n + 16 + chol_ws_elems(n); }
+
+// thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected.  sticky: deferred mode -- the
+// factorisation always runs to the end (A is overwritten either way), a rejection is recorded in *sticky.
+static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in = nullptr, int *sticky = nullptr)
 {
     const int n = (int)n64;
-    if (n > 128 || m < n) return 0;
-    double *ws = (double *)scratch(stream, SCRATCH_MISC, ((size_t)m * n + 4 * (size_t)n * n + 16) * 8);
+    if (n > CHOL_MAX || m < n) return 0;
+    double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, qr_ws_elems(m, n) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *Q1 = ws, *G = Q1 + (size_t)m * n, *R1 = G + n * n, *R2 = R1 + n * n, *Qtop = R2 + n * n;
     int *status = (int *)(Qtop + n * n);
+    double *cws = n > CHOL_ONE ? Qtop + n * n + 16 : nullptr;
     int rc;
     if ((rc = small_gemm(n, n, m, A, 1, n, A, n, 1, G, stream))) return rc;              // A^T A
-    if ((rc = launch_chol(G, n, R1, nullptr, status, 1e-6, st))) return rc;             // kappa(A) up to ~1e6
+    if ((rc = chol_inv_any(G, n, R1, nullptr, status, 1e-6, stream, st, cws, sticky))) return rc;       // kappa(A) up to ~1e6
     if ((rc = small_gemm(m, n, n, A, n, 1, R1, n, 1, Q1, stream))) return rc;            // Q1 = A R1^-1
     if ((rc = small_gemm(n, n, m, Q1, 1, n, Q1, n, 1, G, stream))) return rc;            // Q1^T Q1
-    if ((rc = launch_chol(G, n, R2, nullptr, status + 1, 0.5, st))) return rc;          // must be ~identity
+    if ((rc = chol_inv_any(G, n, R2, nullptr, status + 1, 0.5, stream, st, cws, sticky))) return rc;    // must be ~identity
     if ((rc = small_gemm(n, n, n, Q1, n, 1, R2, n, 1, Qtop, stream))) return rc;         // top block of Q
-    hipLaunchKernelGGL(hh_sign_scale_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n,
-                       m == n64 ? 1 : 0, R2);
+    if (n <= CHOL_ONE) {
+        hipLaunchKernelGGL(hh_sign_scale_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n,
+                           m == n64 ? 1 : 0, R2);
+    } else {
+        // beyond one workgroup's LDS: the same modified LU with the working copy in global memory (Qtop itself)
+        hipLaunchKernelGGL(hh_sign_scale_global_kernel, dim3(1), dim3(1024), 0, st, Qtop, n, m == n64 ? 1 : 0, R2);
+    }
     TTSK_LAUNCH_CHECK();
-    int host_status[2] = {1, 1};
-    TTSK_HIP(hipMemcpyAsync(host_status, status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    TTSK_HIP(hipStreamSynchronize(st));
-    if (host_status[0] || host_status[1]) return 0;
+    if (!sticky) {
+        int host_status[2] = {1, 1};
+        TTSK_HIP(hipMemcpyAsync(host_status, status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        TTSK_HIP(hipStreamSynchronize(st));
+        if (host_status[0] || host_status[1]) return 0;
+    }
     if ((rc = small_gemm(m, n, n, Q1, n, 1, R2, n, 1, A, stream))) return rc;            // Q = Q1 R2^-1 S
     return 1;
 }
@@ -890,6 +1008,57 @@ int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, doubl
     const int rc = ttsk_pinv_begin(dev_omega, l, r, rcond, dev_pinv, stream);
     if (rc != TTSK_OK) return rc;
     return ttsk_pinv_end(dev_omega, l, r, rcond, dev_pinv, host_rank, stream);
+}
+
+// One orthogonalisation step of orthogonal_sketch / hmt_sketch (sketch_dispatch.py:160-174) as ONE call without a
+// read-back: Q = qr_thin(Psi_mat pinv(Omega)) (Omega == NULL: qr_thin(Psi_mat)) through the normal equations and
+// CholeskyQR2.  The verdicts of the factorisations (Omega not of full rank / too ill conditioned, Psi_mat Omega^+ too
+// ill conditioned) are NOT waited for: a rejection sets the stream's deferred flag and the numbers in Q are then
+// meaningless; the caller reads the flag once at the end (ttsk_deferred_status) and repeats the sketch on the robust
+// kernels (ttsk_pinv / ttsk_qr_thin).  TTSK_ERR_UNSUPPORTED: ranks beyond 256 or TTSK_FAST_SOLVES=0.
+int ttsk_orth_step(const double *dev_psi, int64_t m, int64_t r2, const double *dev_omega, int64_t l, double *dev_q, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_psi && dev_q && m >= 1 && r2 >= 1, "ttsk_orth_step: bad argument");
+    const int64_t k = dev_omega ? l : r2;
+    TTSK_ARG(k >= 1 && m >= k, "ttsk_orth_step: cannot orthogonalise a %lld x %lld unfolding", (long long)m, (long long)k);
+    int *sticky = deferred_flag(stream);
+    const int64_t nmin = dev_omega ? (l < r2 ? l : r2) : 0;
+    if (!fast_solves() || !sticky || k > CHOL_MAX || nmin > CHOL_MAX || (dev_omega && pinv_rcond(l, r2, -1.0) > 1e-4)) {
+        set_error("ttsk_orth_step: (%lld x %lld, rank %lld) is outside the fast path", (long long)m, (long long)r2, (long long)k);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    const size_t pw = dev_omega ? pinv_ws_elems((int)nmin) + (size_t)r2 * l : 0;
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, (pw + qr_ws_elems(m, (int)k)) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    int rc;
+    if (dev_omega) {
+        double *pinv = ws + pinv_ws_elems((int)nmin);
+        rc = pinv_cholesky_begin(dev_omega, l, r2, pinv, stream, st, ws, sticky);
+        if (rc < 0) return rc;
+        if (rc == 0) { set_error("ttsk_orth_step: pseudo-inverse outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+        if ((rc = small_gemm(m, l, r2, dev_psi, r2, 1, pinv, l, 1, dev_q, stream))) return rc;      // M = Psi_mat Omega^+
+    } else if (dev_q != dev_psi) {
+        TTSK_HIP(hipMemcpyAsync(dev_q, dev_psi, (size_t)m * r2 * 8, hipMemcpyDeviceToDevice, st));
+    }
+    rc = qr_cholesky(dev_q, m, k, stream, st, ws + pw, sticky);
+    if (rc < 0) return rc;
+    if (rc == 0) { set_error("ttsk_orth_step: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+    return TTSK_OK;
+}
+
+// 1 in *host_flag if a fast-path factorisation queued on `stream` by ttsk_orth_step was rejected since the last call
+// (waits for the stream; clears the flag)
+int ttsk_deferred_status(int stream, int *host_flag)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(host_flag, "ttsk_deferred_status: NULL argument");
+    int *sticky = deferred_flag(stream);
+    TTSK_ARG(sticky, "ttsk_deferred_status: no device flag");
+    TTSK_HIP(hipMemcpyAsync(host_flag, sticky, sizeof(int), hipMemcpyDeviceToHost, st));
+    TTSK_HIP(hipMemsetAsync(sticky, 0, sizeof(int), st));
+    TTSK_HIP(hipStreamSynchronize(st));
+    return TTSK_OK;
 }
 
 int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, double *dev_S, double *dev_Vt,

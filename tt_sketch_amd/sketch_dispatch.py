@@ -104,18 +104,28 @@ def get_sketch_method(tensor: Tensor, drm: DRM) -> Callable:
     raise ValueError(f"DRM of type {type(drm)} can't sketch {type(tensor)}")
 
 
-def orth_step(Psi, Omega=None) -> DevArray:
-    """Psi <- Q of thin QR(Psi_mat pinv(Omega)) (reference :160-174), all on the device."""
+def orth_step(Psi, Omega=None, deferred: bool = False) -> DevArray:
+    """Psi <- Q of thin QR(Psi_mat pinv(Omega)) (reference :160-174), all on the device.
+
+    ``deferred``: one library call (``ttsk_orth_step``) that does not wait for the acceptance tests of its
+    factorisations; the caller checks ``ttsk_deferred_status`` once and repeats on the robust path if needed."""
     P = as_dev(Psi).contiguous()
     r1, n, r2 = P.shape
     M = P.reshape(r1 * n, r2)
+    k = r2 if Omega is None else int(as_dev(Omega).shape[0])
+    if r1 * n < k:
+        raise ValueError(f"cannot orthogonalise a {r1 * n} x {k} unfolding: trim the sketch ranks")
+    if deferred:
+        Om = None if Omega is None else as_dev(Omega).contiguous()
+        Q = DevArray.empty((r1 * n, k))
+        nat.call("ttsk_orth_step", ctypes.c_void_p(M.ptr), r1 * n, r2, None if Om is None else ctypes.c_void_p(Om.ptr),
+                 k, ctypes.c_void_p(Q.ptr), 0)
+        return Q.reshape(r1, n, k)
     if Omega is not None:
         M = contract("ij,jk->ik", M, pinv_dev(Omega))
     elif M is P or M.buf is P.buf:
         M = M.copy()                       # QR works in place; keep the caller's Psi intact
     m, k = M.shape
-    if m < k:
-        raise ValueError(f"cannot orthogonalise a {m} x {k} unfolding: trim the sketch ranks")
     nat.call("ttsk_qr_thin", ctypes.c_void_p(M.ptr), m, k, 0)
     return M.reshape(r1, n, k)
 
@@ -158,6 +168,23 @@ def general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DR
 
 def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
                            method: SketchMethod) -> Tuple[List[DevArray], List[DevArray]]:
+    if method in (SketchMethod.hmt, SketchMethod.orthogonal):
+        # Optimistic pass: every orthogonalisation as one call on the fast factorisations, no verdict awaited (the
+        # d - 1 steps are sequential in mu: each blocking read-back drains the queue).  ONE read-back at the end; a
+        # rejected factorisation (rank-deficient Omega, ill-conditioned unfolding) repeats the sketch on the robust path.
+        try:
+            out = _sketch_pass(tensor, left_drm, right_drm, method, deferred=True)
+        except nat.TtskUnsupported:
+            out = None
+        flag = ctypes.c_int(0)
+        nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+        if out is not None and not flag.value:
+            return out
+    return _sketch_pass(tensor, left_drm, right_drm, method, deferred=False)
+
+
+def _sketch_pass(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM, method: SketchMethod,
+                 deferred: bool) -> Tuple[List[DevArray], List[DevArray]]:
     d = len(tensor.shape)
     tensor.prepare_device()
     if method != SketchMethod.hmt:
@@ -201,9 +228,9 @@ def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: D
                          psi_shape=(r1, tensor.shape[mu], r2))
         if mu < d - 1:
             if method == SketchMethod.orthogonal:
-                Psi = orth_step(Psi, Omega_mats[mu])
+                Psi = orth_step(Psi, Omega_mats[mu], deferred)
             elif method == SketchMethod.hmt:
-                Psi = orth_step(Psi, None)
+                Psi = orth_step(Psi, None, deferred)
         Psi_cores.append(as_dev(Psi))
     return Psi_cores, Omega_mats
 
