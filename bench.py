@@ -727,22 +727,28 @@ def bench_c4(args, job):
     for _ in range(reps):
         step()
     nat.call("ttsk_sync", -1)
-    classes = prof_classes(nat, reps, {6: "hash-Gaussian sampling (fast_lazy_gaussian.pyx:52-105,183-202)",
-                                       7: "Psi / Omega segmented sums (sparse_sketch.py:8-69)"})
+    classes = prof_classes(nat, reps, {6: "hash-Gaussian sampling into panels / tables (fast_lazy_gaussian.pyx:52-105,183-202)",
+                                       7: "one pass per mode: stream + DRM rows + segmented sums (sparse_sketch.py:8-69)"})
     nat.call("ttsk_prof_enable", 0)
+    from tt_sketch_amd import sparse_fused
+    plan = dict(sparse_fused.last_plan)
+    # VALU roof of a Gaussian sample: hash (two 64 x 64-bit multiplies = 6 quarter-rate 32-bit multiplies + ~20 integer
+    # ops) + ndtri (central branch: 13 FMAs + a division; tails, 27 %: two logs, a square root, three divisions, 18 FMAs):
+    # ~400 SIMD cycles per 64 samples -> 256 CUs x 4 SIMDs x 2.4 GHz x 64 / 400 = 393 G samples / s
+    VALU_GSAMPLES = 393.0
     for label, c in classes.items():
         work = c.pop("gflop_per_launch") * 1e9          # the class's own work unit per launch
         c.pop("tflops", None)
         if label.startswith("hash"):
-            # VALU roof: one sample = hash (3 x 64-bit multiply-xorshift rounds) + ndtri (central branch: two degree-4/8
-            # polynomial ratios; tails: log, sqrt, two ratios): ~150 fp64 VALU operations; the fp64 vector peak is
-            # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T op/s (FMA = one op)
             c.update(bound="valu", samples_per_launch=work, gsamples_per_s=work / (c["avg_us"] * 1e-6) * 1e-9,
-                     valu_ops_per_sample=150, peak_gsamples_per_s=39.3e3 / 150,
-                     frac=work / (c["avg_us"] * 1e-6) * 1e-9 / (39.3e3 / 150))
+                     peak_gsamples_per_s=VALU_GSAMPLES, frac=work / (c["avg_us"] * 1e-6) * 1e-9 / VALU_GSAMPLES)
         else:
-            c.update(bound="hbm", algorithmic_mb_per_launch=work * 1e-6, achieved_gb_s=work / (c["avg_us"] * 1e-6) * 1e-9,
-                     frac=work / (c["avg_us"] * 1e-6) / (HBM_TBS * 1e12), traffic=load_traffic("sparse_psi_mfma_kernel"))
+            per_pass = plan.get("sampled_columns_per_nonzero", 0) * nnz / max(plan.get("passes", 1), 1)
+            c.update(bound="valu" if per_pass else "hbm", stream_mb_per_launch=work * 1e-6, stream_gb_s=work / (c["avg_us"] * 1e-6) * 1e-9,
+                     hbm_frac=work / (c["avg_us"] * 1e-6) / (HBM_TBS * 1e12),
+                     gsamples_per_s=per_pass / (c["avg_us"] * 1e-6) * 1e-9, peak_gsamples_per_s=VALU_GSAMPLES,
+                     frac=(per_pass / (c["avg_us"] * 1e-6) * 1e-9 / VALU_GSAMPLES) if per_pass else work / (c["avg_us"] * 1e-6) / (HBM_TBS * 1e12),
+                     traffic=load_traffic(c["kernel"]), plan=plan)
     cpu = None
     if not args.no_cpu and job.world == 1:
         # the reference's Psi is O(n_mu nnz) boolean masks (sparse_sketch.py:18,60): nnz = 2e5 takes seconds, 1e7 minutes
@@ -764,11 +770,11 @@ def bench_c4(args, job):
                 dtype="f64", data="synthetic",
                 config=dict(workload="C4: general_sketch of a COO tensor d=5 shape (200,150,100,120,300) nnz=1e7 (resident), "
                                      "SparseGaussianDRM l=10 r=15"),
-                roofline=dict(bound="hbm", kernel="sample_rows_kernel (8 x) + sparse_psi_mfma_kernel (9 x)",
+                roofline=dict(bound="hbm", kernel="sg_pass_kernel (5 x: one per mode)",
                               achieved=nbytes / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s",
                               frac=nbytes / t_step / (HBM_TBS * 1e12), traffic=load_traffic("c4_sketch"),
-                              what="SURVEY 8d bytes 8*nnz*(d+1) = 480 MB / wall time of one sketch; the binding unit is the "
-                                   "fp64 VALU evaluating 1e9 ndtri samples",
+                              what="SURVEY 8d bytes 8*nnz*(d+1) = 480 MB / wall time of one sketch (the per-class entry prices the passes "
+                                   "against the fp64 VALU, which binds: every DRM row of a deep mode is an ndtri evaluation)",
                               gaussian_samples_per_s=samples / t_step, classes=classes,
                               first_call_ms=dict(h2d_and_upload=t_h2d * 1e3, first_sketch_incl_mode_sorts=t_first * 1e3,
                                                  steady_state=t_step * 1e3)),

@@ -190,6 +190,10 @@ int ttsk_inds_to_sparse_sign(const int64_t *host_idx, const uint64_t *shape, int
 int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
                            const uint64_t *shape, int m, size_t N, int rank_min, int rank_max,
                            uint64_t seed, double *dev_out, int stream);
+/* the same samples for EVERY possible prefix: row f of dev_out (prod(shape), rank) belongs to the index row whose
+ * Fortran-order flat index is f (only without the 32-bit wrap of the reference's running product) */
+int ttsk_sparse_normal_table(const uint64_t *shape, int m, int rank_min, int rank_max, uint64_t seed, double *dev_out,
+                             int stream);
 int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
                          const uint64_t *shape, int m, size_t N, int true_rank, int rank_min,
                          int rank_max, int nnz_per_row, uint64_t seed, double *dev_out, int stream);
@@ -224,6 +228,32 @@ int ttsk_sparse_densedrm_gather(const double *dev_mat, int64_t rank, int64_t col
 int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int64_t *dev_perm, size_t N,
                     const double *dev_Lv, int64_t l, const double *dev_Rv, int64_t r,
                     int64_t n, double *dev_psi, int stream);
+
+/* ---- SparseTensor x SparseGaussianDRM without (nnz x rank) panels (csrc/sparse_fused.hip) ----
+ * sparse_gaussian_drm.py:29-44 + sparse_sketch.py:8-69 as one pass per mode over a resident, mode-ordered stream. */
+/* multipliers of the Fortran-order flat index of fast_lazy_gaussian.pyx:60-71 incl. its 32-bit running product (host) */
+int ttsk_sparse_flat_mult(const uint64_t *shape, int m, uint64_t *mult_out);
+/* stream of one mode: record pos = nonzero perm[pos] (perm: ttsk_sparse_sort_mode; NULL = identity): flat index of the
+ * l_m index rows l_rows (prefix, shape l_shape) and of the r_m rows r_rows (suffix as the transposed tensor walks it),
+ * the index of physical row mode_row as int32, the entry.  Rows are physical rows of the (d, N) index matrix. */
+int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                            const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                            const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream);
+/* one DRM factor of a pass: kind 0 = ones (width 1), 1 = table[flat][w] (every possible prefix sampled once:
+ * ttsk_sparse_normal_table), 2 = sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c) + seed)));
+ * flat = src 0: prefix, 1: suffix, 2: prefix + j * mul, 3: suffix + j * mul (the prefix / suffix one mode longer) */
+typedef struct {
+    int kind, w, rank_min, src;
+    uint64_t mul, seed;
+    const double *table;
+} ttsk_sg_factor;
+/* Psi[a, j, c] (+)= sum_{e: j_e = j} val_e A[e, a] B[e, c]   (dev_psi (wA, n, wB), zero-initialised by the caller)
+ * and, with C != NULL, Omega += sum_e val_e C[e, a] B[e, c] (c_left) or sum_e val_e A[e, a] C[e, c]  (dev_omega,
+ * zero-initialised).  Stream in ascending j (ttsk_sparse_mode_stream); dev_j == NULL: one slice.  Widths <= 16.
+ * No atomics: the result is bit-reproducible. */
+int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
+                           int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                           double *dev_psi, double *dev_omega, int stream);
 /* stable sort permutation of the nonzeros by one index row (values < n): perm[i] = id of the i-th
  * nonzero in mode-index order.  Independent of the DRM: computed once per tensor and mode. */
 int ttsk_sparse_sort_mode(const int64_t *dev_idx_row, size_t N, int64_t n, int64_t *dev_perm, int stream);

@@ -976,6 +976,65 @@ def test_orth_step_deferred_flag_on_rank_deficient_input(tsa):
     assert flag.value == 1
 
 
+@pytest.mark.parametrize("case", [
+    # (shape, nnz, l, r, rank_min?) -- small shapes: every factor is a table; large: sampled in the pass; mixed
+    ((7, 6, 5, 8), 300, 3, 5, False),
+    ((40, 30, 20, 25, 35), 20000, 10, 15, False),
+    ((200, 150, 100, 120, 300), 60000, 10, 15, False),
+    ((9, 11), 60, 4, 16, False),
+    ((300, 7, 250), 5000, 16, 13, True),
+    ((5, 4, 3, 6, 2, 7), 4000, 2, 3, False),
+])
+def test_sparse_fused_passes_vs_oracle_and_generator_path(tsa, case, monkeypatch):
+    """csrc/sparse_fused.hip (one pass per mode, DRM rows sampled / gathered where consumed, no atomics) == the oracle's
+    restatement of sparse_gaussian_drm.py:29-44 + sparse_sketch.py:8-69, == the generator path of round 2, and
+    bit-identical from run to run."""
+    shape, nnz, l, r, sliced = case
+    d = len(shape)
+    rng = np.random.default_rng(nnz)
+    idx = np.stack([rng.integers(0, n, nnz) for n in shape]).astype(np.int64)
+    val = rng.standard_normal(nnz)
+    lo_l, lo_r = ((1,) * (d - 1), (2,) * (d - 1)) if sliced else ((0,) * (d - 1), (0,) * (d - 1))
+    hi_l, hi_r = tuple(a + l for a in lo_l), tuple(a + r for a in lo_r)
+    kw = lambda lo, hi: dict(rank_min=lo, rank_max=hi, true_rank=hi)
+    mk = lambda: (tsa.SparseGaussianDRM(hi_l, shape, False, seed=3, **kw(lo_l, hi_l)),
+                  tsa.SparseGaussianDRM(hi_r, shape, True, seed=4, **kw(lo_r, hi_r)))
+    T = tsa.SparseTensor(shape, idx, val)
+    ld, rd = mk()
+    from tt_sketch_amd import sparse_fused
+    assert sparse_fused.try_sparse_gauss_sketch(T, ld, rd, tsa.SketchMethod.streaming) is not None
+    sk = tsa.general_sketch(T, ld, rd, tsa.SketchMethod.streaming)
+    oP, oO = orc.general_sketch("sparse", (shape, idx, val), orc.HashGaussDrm(3, shape, False, lo_l, hi_l),
+                                orc.HashGaussDrm(4, shape, True, lo_r, hi_r), "streaming")
+    got = sk.Psi_cores + sk.Omega_mats
+    for a, b in zip(got, oP + oO):
+        assert a.shape == b.shape and rel(a, b) < 1e-11, (a.shape, rel(a, b))
+    again = tsa.general_sketch(tsa.SparseTensor(shape, idx, val), *mk(), tsa.SketchMethod.streaming)
+    for a, b in zip(got, again.Psi_cores + again.Omega_mats):
+        assert np.array_equal(a, b)                    # fixed summation order: bit-reproducible
+    monkeypatch.setenv("TTSK_SPARSE_FUSED", "0")
+    old = tsa.general_sketch(tsa.SparseTensor(shape, idx, val), *mk(), tsa.SketchMethod.streaming)
+    for a, b in zip(got, old.Psi_cores + old.Omega_mats):
+        assert rel(a, b) < 1e-11
+
+
+def test_sparse_fused_samples_are_bit_identical_to_the_sampler(tsa):
+    """One nonzero per first-mode slice with entry 1: Psi_0[0, j, :] IS the right DRM row of that nonzero -- the
+    samples made inside the pass (table and in-pass kinds) against ttsk_inds_to_normal, bit for bit."""
+    from tt_sketch_amd.drm.fast_lazy_gaussian import inds_to_normal
+    for shape in [(50, 4, 3), (64, 300, 200, 100)]:
+        d, n0 = len(shape), shape[0]
+        rng = np.random.default_rng(n0)
+        idx = np.stack([np.arange(n0)] + [rng.integers(0, n, n0) for n in shape[1:]]).astype(np.int64)
+        T = tsa.SparseTensor(shape, idx, np.ones(n0))
+        ld = tsa.SparseGaussianDRM(5, shape, False, seed=11)
+        rd = tsa.SparseGaussianDRM(12, shape, True, seed=12)
+        sk = tsa.general_sketch(T, ld, rd, tsa.SketchMethod.streaming)
+        # R_0: the right DRM's matrix with d - 1 index rows of the transposed tensor, seed (d - 2 + seed) mod 2^63
+        want = inds_to_normal(idx[::-1][:d - 1], shape[::-1][:d - 1], 0, 12, (d - 2 + rd.seed) % 2**63)
+        assert np.array_equal(sk.Psi_cores[0][0], want)
+
+
 def _chain_step_case(entry, case, seed_salt=0):
     import ctypes
     from tt_sketch_amd import _native as nat

@@ -7,139 +7,9 @@
 #include <cmath>
 #include <vector>
 #include "common.h"
+#include "sampler_dev.h"
 
 namespace ttsk {
-
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t r)
-{
-    r += 0x4BE98134A5976FD3ULL;
-    r ^= r >> 30;
-    r *= 0xBF58476D1CE4E5B9ULL;
-    r ^= r >> 27;
-    r *= 0x94D049BB133111EBULL;
-    r ^= r >> 31;
-    return r;
-}
-
-constexpr int MAX_MODES = 32;
-struct IndexMap {
-    int m;
-    int row_order[MAX_MODES];
-    uint64_t mult[MAX_MODES];  // Fortran-order multipliers with the reference's int32 wrap
-    int64_t row_stride;
-};
-
-// fast_lazy_gaussian.pyx:60-71 -- `cdef int prod` is 32-bit and sign-extends.
-static int make_index_map(const uint64_t *shape, int m, int64_t row_stride, const int *row_order,
-                          IndexMap *im)
-{
-    TTSK_ARG(m >= 1 && m <= MAX_MODES, "hash sampler supports 1..%d index rows, got %d", MAX_MODES, m);
-    im->m = m;
-    im->row_stride = row_stride;
-    int32_t prod = (int32_t)shape[0];
-    for (int i = 0; i < m; ++i) {
-        im->row_order[i] = row_order ? row_order[i] : i;
-        if (i == 0) { im->mult[0] = 1; continue; }
-        im->mult[i] = (uint64_t)(int64_t)prod;
-        prod = (int32_t)((uint64_t)(int64_t)prod * shape[i]);
-    }
-    return TTSK_OK;
-}
-
-__device__ __forceinline__ uint64_t flat_index(const int64_t *idx, const IndexMap &im, size_t e)
-{
-    uint64_t f = 0;
-    for (int i = 0; i < im.m; ++i)
-        f += (uint64_t)idx[(int64_t)im.row_order[i] * im.row_stride + (int64_t)e] * im.mult[i];
-    return f;
-}
-
-__device__ __forceinline__ uint64_t rand_bits(uint64_t flat, int col, uint64_t seed)
-{
-    uint64_t salt = mix64((uint64_t)col) + seed;
-    uint64_t h = mix64(flat + salt);
-    return (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;  // exponent field 001x..., pyx:91-101
-}
-
-// frexp(x)*2-1 for a normal positive double: the 52 mantissa bits as a fraction in [0,1)
-__device__ __forceinline__ double mant_unit(uint64_t bits)
-{
-    return __longlong_as_double((bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL) - 1.0;
-}
-
-__device__ double ndtri_dev(double y0)
-{
-    const double s2pi = 2.50662827463100050242E0;
-    const double expm2 = 0.13533528323661269189;
-    if (y0 == 0.0) return -INFINITY;
-    if (y0 == 1.0) return INFINITY;
-    int code = 1;
-    double y = y0;
-    if (y > 1.0 - expm2) { y = 1.0 - y; code = 0; }
-    if (y > expm2) {
-        y -= 0.5;
-        double y2 = y * y;
-        double p = -5.99633501014107895267E1;
-        p = p * y2 + 9.80010754185999661536E1;
-        p = p * y2 - 5.66762857469070293439E1;
-        p = p * y2 + 1.39312609387279679503E1;
-        p = p * y2 - 1.23916583867381258016E0;
-        double q = y2 + 1.95448858338141759834E0;
-        q = q * y2 + 4.67627912898881538453E0;
-        q = q * y2 + 8.63602421390890590575E1;
-        q = q * y2 - 2.25462687854119370527E2;
-        q = q * y2 + 2.00260212380060660359E2;
-        q = q * y2 - 8.20372256168333339912E1;
-        q = q * y2 + 1.59056225126211695515E1;
-        q = q * y2 - 1.18331621121330003142E0;
-        double x = y + y * (y2 * p / q);
-        return x * s2pi;
-    }
-    double x = sqrt(-2.0 * log(y));
-    double x0 = x - log(x) / x;
-    double z = 1.0 / x;
-    double p, q;
-    if (x < 8.0) {
-        p = 4.05544892305962419923E0;
-        p = p * z + 3.15251094599893866154E1;
-        p = p * z + 5.71628192246421288162E1;
-        p = p * z + 4.40805073893200834700E1;
-        p = p * z + 1.46849561928858024014E1;
-        p = p * z + 2.18663306850790267539E0;
-        p = p * z - 1.40256079171354495875E-1;
-        p = p * z - 3.50424626827848203418E-2;
-        p = p * z - 8.57456785154685413611E-4;
-        q = z + 1.57799883256466749731E1;
-        q = q * z + 4.53907635128879210584E1;
-        q = q * z + 4.13172038254672030440E1;
-        q = q * z + 1.50425385692907503408E1;
-        q = q * z + 2.50464946208309415979E0;
-        q = q * z - 1.42182922854787788574E-1;
-        q = q * z - 3.80806407691578277194E-2;
-        q = q * z - 9.33259480895457427372E-4;
-    } else {
-        p = 3.23774891776946035970E0;
-        p = p * z + 6.91522889068984211695E0;
-        p = p * z + 3.93881025292474443415E0;
-        p = p * z + 1.33303460815807542389E0;
-        p = p * z + 2.01485389549179081538E-1;
-        p = p * z + 1.23716634817820021358E-2;
-        p = p * z + 3.01581553508235416007E-4;
-        p = p * z + 2.65806974686737550832E-6;
-        p = p * z + 6.23974539184983293730E-9;
-        q = z + 6.02427039364742014255E0;
-        q = q * z + 3.67983563856160859403E0;
-        q = q * z + 1.37702099489081330271E0;
-        q = q * z + 2.16236993594496635890E-1;
-        q = q * z + 1.34204006088543189037E-2;
-        q = q * z + 3.28014464682127739104E-4;
-        q = q * z + 2.89247864745380683936E-6;
-        q = q * z + 6.79019408009981274425E-9;
-    }
-    double x1 = z * p / q;
-    x = x0 - x1;
-    return code ? -x : x;
-}
 
 // ndtri over a workgroup's 256 samples.  27 % of uniform samples fall in the tails of ndtri (two
 // software logs, a square root, three divisions), so practically every wave would execute both
@@ -466,6 +336,30 @@ int ttsk_sparse_normal_dev(const int64_t *dev_idx, int64_t row_stride, const int
         return TTSK_OK;
     }
     launch_sample<1>(dev_idx, im, N, rank_min, w, seed, dev_out, st);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+// The samples of EVERY possible index prefix: row f of the table is what ttsk_sparse_normal_dev returns for an index
+// row whose flat index (fast_lazy_gaussian.pyx:60-71) is f.  Only where that flat index is a bijection onto
+// [0, prod(shape)): no 32-bit wrap of the running product (TTSK_ERR_UNSUPPORTED otherwise).
+int ttsk_sparse_normal_table(const uint64_t *shape, int m, int rank_min, int rank_max, uint64_t seed, double *dev_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(shape && dev_out && rank_max > rank_min && rank_min >= 0, "ttsk_sparse_normal_table: bad argument");
+    IndexMap im;
+    int rc = make_index_map(shape, m, 0, nullptr, &im);
+    if (rc) return rc;
+    double prod = 1.0;
+    for (int i = 0; i < m; ++i) prod *= (double)shape[i];
+    if (!(prod < 2147483648.0)) {
+        set_error("ttsk_sparse_normal_table: %g prefixes: the reference's 32-bit running product wraps", prod);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    const bool prof = prof_on();
+    if (prof) prof_open_named(st, PROF_SAMPLER, prod * (rank_max - rank_min), "sample_rows_kernel (prefix table)");
+    launch_sample<1>(nullptr, im, (size_t)prod, rank_min, rank_max - rank_min, seed, dev_out, st);
+    if (prof) prof_close(st);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

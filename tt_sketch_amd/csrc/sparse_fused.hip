@@ -1,0 +1,407 @@
+// SparseTensor x SparseGaussianDRM, streaming sketch, without the (nnz x rank) panels.
+//
+//   reference: sparse_gaussian_drm.py:29-44 (G[e, k] = ndtri(u(hash(flat_e + hash(k) + seed)))),
+//              sparse_sketch.py:8-69      (Psi[:, j, :] = sum_{e: idx_mu[e] = j} val_e L[:, e] R[:, e]^T,
+//                                          Omega = (L o val) R^T)
+//
+// The generator path (sampler.hip + sparse.hip) materialises every L_mu / R_mu as an (nnz x rank) matrix and
+// reads it back through the mode permutation: ~18 GB of traffic at C4 for 480 MB of input.  Here one PASS per
+// mode mu walks the nonzeros in mode-mu order ONCE and produces Psi_mu -- and one Omega riding along -- with
+// every DRM row made where it is consumed:
+//   * the nonzeros of a mode are a resident STREAM of records (flat prefix index, flat suffix index, mode
+//     index, value) in mode order, built once per tensor (ttsk_sparse_mode_stream): 28 bytes per nonzero and
+//     pass, read sequentially; the flat index of the prefix one mode longer (for the Omega that shares the right
+//     factor) follows from the record by one multiply-add;
+//   * a DRM factor with few possible prefixes / suffixes (the shallow modes: 200 or 30 000 rows at C4) is a
+//     TABLE sampled once per sketch and gathered from L2; a deep one is SAMPLED in the pass, bit-identically
+//     (same hash, same Cephes ndtri): a wave stages 32 nonzeros, computes the central branch of ndtri in place
+//     and queues the tail samples in LDS so that only full waves pay for the tail code (as sample_rows_kernel);
+//   * the products run on the matrix cores from the staged tile: lane (x, q) of k-block b holds val A[e][x] and
+//     B[e][x] of nonzero e = 4 b + q, the operand layout of v_mfma_f64_16x16x4 (ranks <= 16 per factor);
+//   * NO atomics: a wave stores the slices that lie inside its stretch, its first and last (shared) slices go to
+//     per-wave partial blocks that a second kernel adds in wave order -- the sketch is bit-reproducible.
+#include <cstdlib>
+#include "sampler_dev.h"
+
+namespace ttsk {
+
+struct SgF {
+    int kind;            // 0: ones (width 1), 1: table gathered by flat index, 2: sampled in the pass
+    int w;               // columns (<= 16)
+    int rank_min;
+    int src;             // flat index: 0 = prefix, 1 = suffix, 2 = prefix + j * mul, 3 = suffix + j * mul
+    uint64_t mul, seed;
+    const double *table;
+};
+
+struct SgPass {
+    const uint64_t *fl, *fr;
+    const int32_t *jj;
+    const double *val;
+    size_t N, chunk;     // nonzeros, nonzeros per wave (multiple of 32)
+    int64_t n;           // slices of Psi
+    SgF f[3];            // Psi = (val A) (x) B by slice; Omega = (val C) (x) B  (c_left)  or  (val A) (x) C
+    int c_left, has_om;
+    int off[3], tcols;   // column offsets of the factors in the staged tile, its row length
+    int qcols;           // columns of the sampled factors: the tail queue holds at most SG_T * qcols slots
+    double *psi;         // [wA][n][wB]
+    double *part_psi;    // [wave][2][wA * wB]
+    int *part_j;         // [wave][3]: first slice, last slice (= first if none), 1 if the last partial exists
+    double *part_om;     // [wave][wOl * wOr]
+};
+
+constexpr int SG_T = 32;         // nonzeros per staged tile
+
+// ndtri as a CALL in this kernel: inlined at its two sites it takes the pass kernel to ~230 VGPRs (two waves per SIMD,
+// or 49 spilled registers under a tighter cap); the call costs a few scalar instructions per ~100 of arithmetic.
+__device__ __attribute__((noinline)) double sg_ndtri(double u) { return ndtri_dev(u); }
+
+__device__ __forceinline__ uint64_t sg_flat(const SgF &f, uint64_t fl, uint64_t fr, int j)
+{
+    const uint64_t base = (f.src & 1) ? fr : fl;
+    return (f.src & 2) ? base + (uint64_t)(int64_t)j * f.mul : base;
+}
+
+__global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
+{
+    extern __shared__ double sg_lds[];
+    __shared__ uint64_t salt[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x16 = lane & 15, kq = lane >> 4;
+    if (tid < 48) {
+        const int f = tid >> 4, c = tid & 15;
+        salt[f][c] = mix64((uint64_t)(a.f[f].rank_min + c)) + a.f[f].seed;
+    }
+    __syncthreads();                                   // the only workgroup barrier: waves run free from here
+    const int tcols = a.tcols;
+    // per-wave LDS: tile[SG_T][tcols] | fl[SG_T] | fr[SG_T] | val[SG_T] | j[SG_T] (int) | queue (ushort, SG_T * qcols)
+    const size_t per_wave = (size_t)SG_T * tcols + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * a.qcols + 3) / 4;
+    double *tile = sg_lds + (size_t)wv * per_wave;
+    uint64_t *rfl = (uint64_t *)(tile + SG_T * tcols), *rfr = rfl + SG_T;
+    double *rv = (double *)(rfr + SG_T);
+    int *rj = (int *)(rv + SG_T);
+    unsigned short *q = (unsigned short *)(rj + SG_T);
+
+    const size_t w_id = (size_t)blockIdx.x * 4 + wv;
+    const size_t beg = w_id * a.chunk;
+    const int wA = a.f[0].w, wB = a.f[1].w;
+    const int wOl = a.c_left ? a.f[2].w : wA, wOr = a.c_left ? wB : a.f[2].w;
+    int *pj = a.part_j + w_id * 3;
+    if (beg >= a.N) {                                  // a padding wave of the last workgroup: nothing but zeros for the sums
+        if (lane == 0) { pj[0] = 0x7fffffff; pj[1] = 0x7fffffff; pj[2] = 0; }
+        if (a.has_om)
+            for (int t = lane; t < wOl * wOr; t += 64) a.part_om[w_id * (size_t)(wOl * wOr) + t] = 0.0;
+        return;
+    }
+    const size_t end = beg + a.chunk < a.N ? beg + a.chunk : a.N;
+    const int jfirst = a.jj ? a.jj[beg] : 0;
+    v4d accP = {0.0, 0.0, 0.0, 0.0}, accO = {0.0, 0.0, 0.0, 0.0};
+    int cur = jfirst;
+    bool first_done = false;
+
+    // store the finished slice k: the wave's first slice and (final) its last one go to the partial blocks
+    auto flush = [&](int k, bool final) {
+        double *dst;
+        int64_t stride_a;
+        if (!first_done && k == jfirst) {
+            dst = a.part_psi + (w_id * 2) * (size_t)(wA * wB);
+            stride_a = wB;
+            first_done = true;
+        } else if (final) {
+            dst = a.part_psi + (w_id * 2 + 1) * (size_t)(wA * wB);
+            stride_a = wB;
+            if (lane == 0) { pj[1] = k; pj[2] = 1; }
+        } else {
+            dst = a.psi + (size_t)k * wB;
+            stride_a = (int64_t)a.n * wB;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int aa = 4 * t + kq;
+            if (aa < wA && x16 < wB) dst[aa * stride_a + x16] = accP[t];
+            accP[t] = 0.0;
+        }
+    };
+    if (lane == 0) { pj[0] = jfirst; pj[1] = jfirst; pj[2] = 0; }
+
+    // the records of the NEXT tile travel while this one is worked on
+    const int t32 = lane & 31, half = lane >> 5;
+    auto rec_load = [&](size_t t0, uint64_t &xfl, uint64_t &xfr, int &xj, double &xv) {
+        const size_t pos = t0 + t32;
+        const bool in = pos < end;
+        xfl = (in && a.fl) ? a.fl[pos] : 0;
+        xfr = (in && a.fr) ? a.fr[pos] : 0;
+        xj = in ? (a.jj ? a.jj[pos] : 0) : -1;
+        xv = in ? a.val[pos] : 0.0;
+    };
+    uint64_t nx_fl, nx_fr;
+    int nx_j;
+    double nx_v;
+    rec_load(beg, nx_fl, nx_fr, nx_j, nx_v);
+    for (size_t t0 = beg; t0 < end; t0 += SG_T) {
+        // ---- (1) the records of the tile
+        const uint64_t my_fl = nx_fl, my_fr = nx_fr;
+        const int my_j = nx_j;
+        const bool valid = my_j >= 0;
+        if (lane < SG_T) {
+            rfl[lane] = my_fl; rfr[lane] = my_fr;
+            rv[lane] = nx_v;
+            rj[lane] = my_j;
+        }
+        rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
+        __builtin_amdgcn_wave_barrier();
+        // ---- (2) the factors into the tile
+        int qn = 0;
+#pragma unroll 1
+        for (int f = 0; f < 3; ++f) {
+            const SgF &F = a.f[f];
+            if (F.kind == 2) {
+                const uint64_t flat = sg_flat(F, my_fl, my_fr, my_j);
+                for (int ci = 0; 2 * ci < F.w; ++ci) {          // the same trip count in both halves: the ballots below are wave-wide
+                    const int c = 2 * ci + half;
+                    const bool act = valid && c < F.w;
+                    const uint64_t h = mix64(flat + salt[f][c & 15]);
+                    const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
+                    const double u = mant_unit(bits);
+                    const double expm2 = 0.13533528323661269189;
+                    const int slot = t32 * tcols + a.off[f] + c;
+                    const bool central = u > expm2 && u <= 1.0 - expm2;
+                    const bool tail = act && !central;
+                    if (act && central) tile[slot] = sg_ndtri(u);
+                    const unsigned long long m = __ballot(tail);
+                    if (tail) {
+                        tile[slot] = u;
+                        q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)slot;
+                    }
+                    qn += __popcll(m);
+                }
+            } else if (F.kind == 1) {
+                // table rows: lane (row group lane >> 4, column x16); all eight loads in flight before the first store
+                double g[SG_T / 4];
+#pragma unroll
+                for (int i = 0; i < SG_T / 4; ++i) {
+                    const int t = 4 * i + kq;
+                    const uint64_t flat = sg_flat(F, rfl[t], rfr[t], rj[t]);
+                    g[i] = (x16 < F.w && rj[t] >= 0) ? F.table[flat * (uint64_t)F.w + x16] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < SG_T / 4; ++i)
+                    if (x16 < F.w) tile[(4 * i + kq) * tcols + a.off[f] + x16] = g[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- (3) the tail samples, a full wave at a time
+        for (int i = 0; i < qn; i += 64) {
+            if (i + lane < qn) {
+                const int slot = q[i + lane];
+                tile[slot] = sg_ndtri(tile[slot]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- (4) the products: k-block b = nonzeros 4 b .. 4 b + 3 of the tile
+#pragma unroll 2
+        for (int b = 0; b < SG_T / 4; ++b) {
+            const int e = 4 * b + kq;
+            const int je = rj[e];
+            const bool ok = je >= 0;
+            const double v = rv[e];
+            const double *row = tile + e * tcols;
+            double av = a.f[0].kind ? (ok && x16 < wA ? row[a.off[0] + x16] : 0.0) : (x16 == 0 ? 1.0 : 0.0);
+            const double bv = a.f[1].kind ? (ok && x16 < wB ? row[a.off[1] + x16] : 0.0) : (x16 == 0 ? 1.0 : 0.0);
+            av *= v;
+            if (a.has_om) {
+                const double cv = (ok && x16 < a.f[2].w) ? row[a.off[2] + x16] : 0.0;
+                accO = a.c_left ? mfma16(cv * v, bv, accO) : mfma16(av, cv, accO);
+            }
+            if (__ballot(ok && je != cur) == 0ull) {
+                accP = mfma16(av, bv, accP);
+            } else {
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int okq = __shfl((int)ok, 16 * qq);
+                    const int jq = __shfl(je, 16 * qq);
+                    if (!okq) continue;
+                    if (jq != cur) {
+                        flush(cur, false);
+                        cur = jq;
+                    }
+                    accP = mfma16(kq == qq ? av : 0.0, bv, accP);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    flush(cur, true);
+    if (a.has_om) {
+        double *dst = a.part_om + w_id * (size_t)(wOl * wOr);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int aa = 4 * t + kq;
+            if (aa < wOl && x16 < wOr) dst[aa * wOr + x16] = accO[t];
+        }
+    }
+}
+
+// Psi[:, j, :] += the partial blocks of slice j, waves in ascending order (first-slice partials, then last-slice
+// partials): one workgroup per slice, one thread per (a, c); the waves of a slice by bisection (part_j is sorted).
+__global__ __launch_bounds__(256) void sg_psi_reduce_kernel(const double *__restrict__ part, const int *__restrict__ pj, int waves,
+                                                            int wA, int wB, int64_t n, double *__restrict__ psi)
+{
+    const int cells = wA * wB;
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        auto lower = [&](int col, int64_t key) {           // first wave with pj[w][col] >= key
+            int lo = 0, hi = waves;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pj[mid * 3 + col] < key) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const int f0 = lower(0, j), f1 = lower(0, j + 1), l0 = lower(1, j), l1 = lower(1, j + 1);
+        if (f0 == f1 && l0 == l1) continue;
+        for (int cell = threadIdx.x; cell < cells; cell += 256) {
+            double acc = 0.0;
+            for (int w = f0; w < f1; ++w) acc += part[((size_t)w * 2) * cells + cell];
+            for (int w = l0; w < l1; ++w)
+                if (pj[w * 3 + 2]) acc += part[((size_t)w * 2 + 1) * cells + cell];
+            const int aa = cell / wB, c = cell - aa * wB;
+            psi[((size_t)aa * n + j) * wB + c] += acc;
+        }
+    }
+}
+
+// out[t] += sum_w part[w][t] in wave order
+__global__ __launch_bounds__(256) void sg_om_reduce_kernel(const double *__restrict__ part, int waves, int cells, double *__restrict__ out)
+{
+    const int t = blockIdx.x;
+    double acc = 0.0;
+    for (int w = threadIdx.x; w < waves; w += 256) acc += part[(size_t)w * cells + t];
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[t] += red[0];
+}
+
+// the resident stream of one mode: record pos = nonzero perm[pos]
+__global__ void sg_stream_kernel(const int64_t *__restrict__ idx, IndexMap lm, IndexMap rm, int64_t mode_off,
+                                 const int64_t *__restrict__ perm, const double *__restrict__ val, size_t N, uint64_t *__restrict__ fl,
+                                 uint64_t *__restrict__ fr, int32_t *__restrict__ jj, double *__restrict__ vv)
+{
+    for (size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pos < N; pos += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = perm ? (size_t)perm[pos] : pos;
+        fl[pos] = lm.m ? flat_index(idx, lm, e) : 0;
+        fr[pos] = rm.m ? flat_index(idx, rm, e) : 0;
+        jj[pos] = (int32_t)idx[mode_off + (int64_t)e];
+        vv[pos] = val[e];
+    }
+}
+
+}  // namespace ttsk
+
+using namespace ttsk;
+
+extern "C" {
+
+int ttsk_sparse_flat_mult(const uint64_t *shape, int m, uint64_t *mult_out)
+{
+    TTSK_ARG(shape && mult_out, "ttsk_sparse_flat_mult: NULL argument");
+    IndexMap im;
+    int rc = make_index_map(shape, m, 0, nullptr, &im);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) mult_out[i] = im.mult[i];
+    return TTSK_OK;
+}
+
+int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                            const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                            const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_idx && dev_val && dev_fl && dev_fr && dev_j && dev_v, "ttsk_sparse_mode_stream: NULL argument");
+    TTSK_ARG(l_m >= 0 && r_m >= 0 && mode_row >= 0, "ttsk_sparse_mode_stream: bad argument");
+    IndexMap lm{}, rm{};
+    int rc;
+    if (l_m && (rc = make_index_map(l_shape, l_m, row_stride, l_rows, &lm))) return rc;
+    if (r_m && (rc = make_index_map(r_shape, r_m, row_stride, r_rows, &rm))) return rc;
+    if (N == 0) return TTSK_OK;
+    size_t blocks = (N + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(sg_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dev_idx, lm, rm, (int64_t)mode_row * row_stride, dev_perm,
+                       dev_val, N, dev_fl, dev_fr, dev_j, dev_v);
+    TTSK_LAUNCH_CHECK();
+    return TTSK_OK;
+}
+
+int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
+                           int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                           double *dev_psi, double *dev_omega, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_val && dev_psi && n >= 1, "ttsk_sparse_gauss_pass: NULL argument");
+    TTSK_ARG(dev_j || n == 1, "ttsk_sparse_gauss_pass: a NULL mode index means a single slice");
+    TTSK_ARG(!C || dev_omega, "ttsk_sparse_gauss_pass: an Omega factor needs an output");
+    if (N == 0) return TTSK_OK;
+    SgPass a{};
+    a.fl = dev_fl; a.fr = dev_fr; a.jj = dev_j; a.val = dev_val; a.N = N; a.n = n;
+    const ttsk_sg_factor *fs[3] = {A, B, C};
+    int cols = 0;
+    for (int i = 0; i < 3; ++i) {
+        SgF &F = a.f[i];
+        if (!fs[i]) { F.kind = 0; F.w = 1; continue; }
+        F.kind = fs[i]->kind; F.w = fs[i]->kind ? fs[i]->w : 1; F.rank_min = fs[i]->rank_min; F.src = fs[i]->src;
+        F.mul = fs[i]->mul; F.seed = fs[i]->seed; F.table = fs[i]->table;
+        TTSK_ARG(F.kind >= 0 && F.kind <= 2 && F.w >= 1 && F.w <= 16, "ttsk_sparse_gauss_pass: factor %d: kind %d, width %d", i, F.kind, F.w);
+        TTSK_ARG(F.kind != 1 || F.table, "ttsk_sparse_gauss_pass: table factor without a table");
+        TTSK_ARG(!((F.src & 1) ? !dev_fr : !dev_fl) || F.kind == 0, "ttsk_sparse_gauss_pass: factor %d needs a flat index stream", i);
+        a.off[i] = cols;
+        if (F.kind) cols += F.w;
+        if (F.kind == 2) a.qcols += F.w;
+    }
+    a.has_om = C != nullptr;
+    a.c_left = c_left;
+    a.tcols = cols > 0 ? cols : 1;
+    a.psi = dev_psi;
+    // waves: what is resident at once (3 workgroups of 4 waves per CU: 141 VGPRs, <= 53 KB of LDS each), so that the
+    // grid is one even round; stretches of whole tiles
+    static const size_t resident = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return (size_t)v * 12;
+    }();
+    size_t waves = resident;
+    size_t chunk = ((N + waves - 1) / waves + SG_T - 1) / SG_T * SG_T;
+    if (chunk < 8 * SG_T) chunk = 8 * SG_T;
+    waves = (N + chunk - 1) / chunk;
+    const size_t blocks = (waves + 3) / 4;
+    const size_t wtot = blocks * 4;
+    a.chunk = chunk;
+    const int wA = a.f[0].w, wB = a.f[1].w;
+    const int cellsP = wA * wB, cellsO = a.has_om ? (c_left ? a.f[2].w * wB : wA * a.f[2].w) : 0;
+    char *ws = (char *)scratch(stream, SCRATCH_MISC, wtot * ((size_t)(2 * cellsP + cellsO) * 8 + 16) + 256);
+    if (!ws) return TTSK_ERR_HIP;
+    a.part_psi = (double *)ws;
+    a.part_om = a.part_psi + wtot * 2 * cellsP;
+    a.part_j = (int *)(a.part_om + wtot * (size_t)cellsO);
+    const size_t per_wave = (size_t)SG_T * a.tcols + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * a.qcols + 3) / 4;
+    const size_t lds = per_wave * 4 * 8;
+    static bool attr = false;
+    if (!attr) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+    }
+    const bool prof = prof_on();
+    if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");
+    hipLaunchKernelGGL(sg_pass_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    TTSK_LAUNCH_CHECK();
+    const int64_t rb = n < 4096 ? n : 4096;
+    hipLaunchKernelGGL(sg_psi_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, a.part_psi, a.part_j, (int)wtot, wA, wB, n, dev_psi);
+    TTSK_LAUNCH_CHECK();
+    if (a.has_om) {
+        hipLaunchKernelGGL(sg_om_reduce_kernel, dim3((unsigned)cellsO), dim3(256), 0, st, a.part_om, (int)wtot, cellsO, dev_omega);
+        TTSK_LAUNCH_CHECK();
+    }
+    if (prof) prof_close(st);
+    return TTSK_OK;
+}
+
+}  // extern "C"

@@ -238,7 +238,9 @@ def _sketch_pass(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM, method
 def general_sketch(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
                    method: SketchMethod) -> SketchContainer:
     """Sketch on the device, result copied to a host ``SketchContainer``."""
-    from . import tt_fused
+    from . import sparse_fused, tt_fused
     fused = tt_fused.try_stream_sketch(tensor, left_drm, right_drm, method)
+    if fused is None:
+        fused = sparse_fused.try_sparse_gauss_sketch(tensor, left_drm, right_drm, method)
     Psi, Omega = fused if fused is not None else general_sketch_device(tensor, left_drm, right_drm, method)
     return SketchContainer(Psi, Omega)
