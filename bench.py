@@ -356,6 +356,25 @@ def bench_c3(args, job):
         cores_per_s_r53 = D * B * 20 / (time.perf_counter() - t1)
         del out53, plan53, right53
 
+    check = None
+    if args.check and strong:
+        # the sketch of the WHOLE job (sum over every TT of every rank): local sum + one all-reduce, untimed.  The
+        # same for every N: what the N = 2 test compares with the N = 1 run.
+        total = DevArray.empty((plan.size + (plan.size & 1),))
+        if n_mine == 0:
+            nat.call("ttsk_memset", P(total.ptr), 0, ctypes.c_size_t(plan.size * 8), 0)
+        else:
+            for b in range(n_mine):
+                nat.call("ttsk_axpby", P(total.ptr), P(outs[0].ptr + 8 * b * stride), 1.0, 1.0 if b else 0.0,
+                         ctypes.c_size_t(plan.size), 0)
+        if comm_on:
+            nat.call("ttsk_stream_wait", cs, 0)
+            nat.call("ttsk_comm_allreduce_sum", P(total.ptr), ctypes.c_size_t(plan.size), cs)
+        nat.call("ttsk_sync", -1)
+        h = total.get()[:plan.size]
+        probe = np.random.default_rng(12345).standard_normal(plan.size)
+        check = dict(norm=float(np.linalg.norm(h)), probe=float(h @ probe), head=[float(x) for x in h[:4]])
+
     result = None
     if rank == 0:
         fl = algorithmic_flops(shape, (S_IN,) * (D - 1), (L_RANK,) * (D - 1), (R_RANK,) * (D - 1))
@@ -433,6 +452,8 @@ def bench_c3(args, job):
                                   t_total_ms_incl_drm_sampling=api_ms, tt_cores_per_s_right_rank_53=cores_per_s_r53,
                                   sketch_bytes=plan.size * 8),
                       roofline=roofline, cpu_baseline=cpu, parity_rel_err_vs_oracle=parity)
+        if check is not None:
+            result["sketch_check"] = check
     return result
 
 
@@ -886,6 +907,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--items", type=int, default=128, help="--scaling strong: TTs in the fixed job")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--check", action="store_true",
+                    help="--scaling strong: also print norm / probe of the sketch of the whole job (identical for every N)")
     ap.add_argument("--no-extra", action="store_true", help="default config only: skip the c2 / c4 / c5 / solves / ref150 sub-records")
     ap.add_argument("--batch", type=int, default=32, help="TTs per batched pass (ttsk_tt_sketch_batch; 32 = 8 workgroups x 25 slices per tensor in the fused chain step)")
     ap.add_argument("--inflight", type=int, default=2,

@@ -68,8 +68,8 @@ print("sharded ok")
 def test_sharded_entry_points_with_one_rank(tmp_path):
     try:
         res = _run(SHARDED % dict(root=ROOT), env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TTSK_RDV_DIR=str(tmp_path / "rdv")))
-    except subprocess.TimeoutExpired:
-        pytest.skip("RCCL communicator set-up did not return within the time limit on this box")
+    except subprocess.TimeoutExpired as exc:        # a hang is a failure, not a skip (subprocess.run has killed and reaped the child)
+        pytest.fail(f"RCCL communicator set-up did not return within the time limit: stderr {(exc.stderr or b'')[-3000:]!r}")
     assert res.returncode == 0 and "sharded ok" in res.stdout, (res.stdout[-500:], res.stderr[-3000:])
 
 
@@ -97,13 +97,21 @@ def test_failed_rccl_init_exits_cleanly(tmp_path):
     procs = [subprocess.Popen([sys.executable, "-c", FAIL_RANK % dict(root=ROOT)], cwd=ROOT, text=True,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(2)]
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=240))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            pytest.skip("RCCL communicator set-up did not return within the time limit on this box")
+    outs, hung = [], None
+    try:
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=240))
+            except subprocess.TimeoutExpired:
+                hung = p
+                break
+    finally:
+        for p in procs:                      # nobody keeps the GPU: kill and reap every child, hung or not
+            if p.poll() is None:
+                p.kill()
+        tails = [p.communicate()[1][-2000:] if p is hung or p.returncode is None or len(outs) <= i else "" for i, p in enumerate(procs)]
+    if hung is not None:
+        pytest.fail(f"a rank did not return from the failed communicator set-up within the time limit; stderr tails: {tails}")
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (p.returncode, so[-500:], se[-2000:])
         assert "rank done" in so and "init failed" in so, (so[-500:], se[-2000:])
@@ -188,3 +196,63 @@ def test_two_processes_share_the_work(tmp_path):
                 q.kill()
             pytest.fail("a rank did not finish")
         assert p.returncode == 0 and f"rank {r} ok" in so, (so[-300:], se[-2000:])
+
+
+def _visible_gpus():
+    """device count from a child process (hipGetDeviceCount does not initialise a context, but keep pytest's own
+    process out of it anyway)"""
+    code = ("import ctypes; lib = ctypes.CDLL('libamdhip64.so'); n = ctypes.c_int(0); "
+            "rc = lib.hipGetDeviceCount(ctypes.byref(n)); print(n.value if rc == 0 else 0)")
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def test_two_gpus_give_the_one_gpu_sketch():
+    """RCCL with N > 1: `bench.py --gpus 2 --scaling strong` under the driver's launcher on the first
+    box that shows two devices; the sketch of the whole job after the all-reduce must equal the N = 1 run's at 1e-12.
+    Skipped on one-GPU boxes (where this suite has run so far).  The launcher starts the ranks before anything touches
+    a GPU; nothing re-execs."""
+    import json
+    if _visible_gpus() < 2:
+        pytest.skip("needs two visible GPUs")
+    common = ["--scaling", "strong", "--items", "16", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu", "--check"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    port = 29500 + os.getpid() % 2000
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, (two.stdout[-1000:], two.stderr[-3000:])
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    ca, cb = a["sketch_check"], b["sketch_check"]
+    assert abs(ca["norm"] - cb["norm"]) <= 1e-12 * ca["norm"]
+    assert abs(ca["probe"] - cb["probe"]) <= 1e-11 * ca["norm"] * (a["config"]["sketch_bytes"] / 8) ** 0.5
+    for x, y in zip(ca["head"], cb["head"]):
+        assert abs(x - y) <= 1e-12 * max(abs(x), 1e-300) + 1e-12 * ca["norm"] * 1e-3
+
+
+def test_strong_scaling_check_runs_on_one_gpu():
+    """the --check leg itself (local sum, no communicator) and, with the collective path forced on one rank, the
+    all-reduce: both must give the same numbers"""
+    import json
+    common = ["--gpus", "1", "--scaling", "strong", "--items", "8", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu", "--check"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for force in (False, True):
+        e = dict(env, TTSK_BENCH_FORCE_COMM="1") if force else env
+        try:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300,
+                                 env=e, cwd=ROOT)
+        except subprocess.TimeoutExpired as exc:
+            pytest.fail(f"bench.py --check (force_comm={force}) did not finish: {exc}")
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])["sketch_check"])
+    assert abs(outs[0]["norm"] - outs[1]["norm"]) <= 1e-13 * outs[0]["norm"]
+    assert outs[0]["head"] == outs[1]["head"]

@@ -169,6 +169,36 @@ def test_file_rendezvous_carries_the_id_between_processes(tmp_path):
     assert res == [(0, True, True), (1, True, True), (2, True, True)]
 
 
+def test_file_rendezvous_ignores_the_leftovers_of_a_crashed_launch(tmp_path):
+    """a directory that still holds an earlier launch's files (crashed before close(), or a fixed
+    TTSK_RDV_DIR): the new launch must neither read the stale NCCL id nor a stale gather piece, and the directory is
+    gone after a clean close."""
+    import multiprocessing as mp
+    import os
+    d = tmp_path / "rdv"
+    d.mkdir()
+    # what a launch of the old naming scheme and a crashed launch of the new one leave behind
+    (d / "000001_bcast.0").write_bytes(b"\x07" * 128)
+    (d / "000002_gather.1").write_bytes(b"stale")
+    (d / "hello.0").write_bytes(b"deadbeefdeadbeef")
+    (d / "hello.1").write_bytes(b"0123456789abcdef")
+    (d / "hello.2").write_bytes(b"fedcba9876543210")
+    (d / "session").write_bytes(b"aaaaaaaaaaaaaaaa deadbeefdeadbeef 0123456789abcdef fedcba9876543210")
+    (d / "ack.1").write_bytes(b"aaaaaaaaaaaaaaaa deadbeefdeadbeef 0123456789abcdef fedcba9876543210")
+    (d / "aaaaaaaaaaaaaaaa_000001_bcast.0").write_bytes(b"\x09" * 128)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdv_worker, args=(r, 3, str(d), q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True), (2, True, True)]
+    assert not os.path.exists(d)              # the last rank out removed it, leftovers included
+
+
 def test_failed_comm_init_leaves_the_process_exit_clean():
     """ttsk_comm_init with a bad rank / without a device returns an error code, leaves no
     communicator behind (destroy is a no-op, init can be called again) and the interpreter exits 0

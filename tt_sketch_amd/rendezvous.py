@@ -31,7 +31,21 @@ def _parent_key() -> str:
 
 
 class FileRendezvous:
-    """``broadcast`` / ``allgather`` / ``barrier`` of byte strings between the ranks of one node."""
+    """``broadcast`` / ``allgather`` / ``barrier`` of byte strings between the ranks of one node.
+
+    Every launch runs under a fresh SESSION id agreed on by a handshake, and every file of the launch carries it in
+    its name -- a directory that still holds the files of an earlier launch (one that crashed before ``close()``, or a
+    fixed ``TTSK_RDV_DIR`` reused by a long-lived driver) cannot feed a stale payload (an old NCCL id, an old gather
+    piece) to a new rank:
+
+      1. rank r writes ``hello.r`` with a random token of its own (fresh per process);
+      2. rank 0 collects the tokens and publishes ``session`` = (its own random id, the token list);
+      3. rank r accepts a session only if position r of its token list is r's own token (a session built from a stale
+         ``hello.r`` is not) and answers ``ack.r`` = the session id; rank 0 re-reads the hello files and publishes again
+         until every ack names the current session.
+
+    The directory is created 0700 and must belong to the calling user.  ``close()`` removes this rank's files and
+    the last rank out removes the directory."""
 
     def __init__(self, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0):
         if not 0 <= rank < world:
@@ -42,36 +56,93 @@ class FileRendezvous:
         if directory is None:
             key = "_".join((os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
                             _parent_key()))
-            directory = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ttsk_rdv_{key}")
+            directory = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ttsk_rdv_{os.getuid()}_{key}")
         self.dir = directory
-        os.makedirs(self.dir, exist_ok=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.stat(self.dir)
+        if st.st_uid != os.getuid():
+            raise PermissionError(f"rendezvous directory {self.dir} belongs to another user")
+        if st.st_mode & 0o077:
+            os.chmod(self.dir, 0o700)
         self._seq = 0
         self._mine: List[str] = []
+        self.session = self._handshake()
 
-    def _path(self, tag: str, rank: int) -> str:
-        return os.path.join(self.dir, f"{tag}.{rank}")
-
-    def _put(self, tag: str, payload: bytes) -> None:
-        path = self._path(tag, self.rank)
+    # -- files
+    def _write(self, name: str, payload: bytes) -> str:
+        path = os.path.join(self.dir, name)
         tmp = path + f".tmp{os.getpid()}"
         with open(tmp, "wb") as f:
             f.write(payload)
         os.rename(tmp, path)
-        self._mine.append(path)
+        if path not in self._mine:
+            self._mine.append(path)
+        return path
 
-    def _get(self, tag: str, rank: int) -> bytes:
-        path = self._path(tag, rank)
+    def _read(self, name: str) -> Optional[bytes]:
+        try:
+            with open(os.path.join(self.dir, name), "rb") as f:
+                return f.read()
+        except FileNotFoundError:
+            return None
+
+    def _poll(self, what: str, step):
+        """call step() until it returns something other than None"""
         deadline = time.monotonic() + self.timeout
         delay = 1e-4
         while True:
-            try:
-                with open(path, "rb") as f:
-                    return f.read()
-            except FileNotFoundError:
-                if time.monotonic() > deadline:
-                    raise TimeoutError(f"rendezvous: rank {rank} never wrote {path}")
-                time.sleep(delay)
-                delay = min(delay * 2, 0.01)
+            out = step()
+            if out is not None:
+                return out
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: {what} (directory {self.dir})")
+            time.sleep(delay)
+            delay = min(delay * 2, 0.01)
+
+    def _handshake(self) -> str:
+        token = os.urandom(8).hex()
+        self._write(f"hello.{self.rank}", token.encode())
+        if self.rank == 0:
+            sid = os.urandom(8).hex()
+            published: List[Optional[str]] = [None]
+
+            def step():
+                tokens = [self._read(f"hello.{r}") for r in range(self.world)]
+                if any(t is None for t in tokens):
+                    return None
+                line = sid + " " + " ".join(t.decode() for t in tokens)
+                if line != published[0]:                      # first time, or a hello file was replaced by a fresh rank
+                    self._write("session", line.encode())
+                    published[0] = line
+                # an ack counts if it names THIS session and the acknowledging rank's current token (the line may have
+                # been republished since because ANOTHER rank's stale hello was replaced)
+                def good(r):
+                    a = self._read(f"ack.{r}")
+                    parts = a.decode().split() if a is not None else []
+                    return len(parts) == self.world + 1 and parts[0] == sid and parts[1 + r] == tokens[r].decode()
+                return sid if all(good(r) for r in range(1, self.world)) else None
+            return self._poll("the ranks never acknowledged the session", step)
+
+        def step():
+            raw = self._read("session")
+            if raw is None:
+                return None
+            parts = raw.decode().split()
+            if len(parts) != self.world + 1 or parts[1 + self.rank] != token:
+                return None                                   # a session of an earlier launch, or built from my stale hello
+            self._write(f"ack.{self.rank}", raw)
+            return parts[0]
+        return self._poll("rank 0 never published a session naming this rank", step)
+
+    def _path(self, tag: str, rank: int) -> str:
+        return os.path.join(self.dir, f"{self.session}_{tag}.{rank}")
+
+    def _put(self, tag: str, payload: bytes) -> None:
+        self._write(f"{self.session}_{tag}.{self.rank}", payload)
+
+    def _get(self, tag: str, rank: int) -> bytes:
+        name = f"{self.session}_{tag}.{rank}"
+        return self._poll(f"rank {rank} never wrote {name}", lambda: self._read(name))
 
     def _tag(self, name: str) -> str:
         self._seq += 1
@@ -95,16 +166,29 @@ class FileRendezvous:
         self.allgather(b"")
 
     def close(self) -> None:
-        """Every rank has read everything it will ever read once it passes this barrier."""
+        """Every rank has read everything it will ever read once it passes the closing barrier; each rank then removes
+        its own files, says ``bye`` and the last one out removes the directory."""
         try:
             self.barrier()
-            last = self._mine[-1] if self._mine else None
-            for p in self._mine:
-                if p != last:                 # the closing barrier's own files may still be polled by slower ranks
-                    try:
-                        os.remove(p)
-                    except OSError:
-                        pass
         except TimeoutError:
             pass
+        closing = self._path(f"{self._seq:06d}_gather", self.rank)
+        for p in self._mine:
+            if p != closing:                  # the closing barrier's own file may still be polled by slower ranks
+                try:
+                    os.remove(p)
+                except OSError:
+                    pass
         self._mine = []
+        try:
+            with open(os.path.join(self.dir, f"{self.session}_bye.{self.rank}"), "wb"):
+                pass
+            if all(os.path.exists(os.path.join(self.dir, f"{self.session}_bye.{r}")) for r in range(self.world)):
+                for name in os.listdir(self.dir):             # everybody is past the barrier: nothing is read any more
+                    try:
+                        os.remove(os.path.join(self.dir, name))
+                    except OSError:
+                        pass
+                os.rmdir(self.dir)
+        except OSError:
+            pass
