@@ -1035,6 +1035,33 @@ def test_sparse_fused_samples_are_bit_identical_to_the_sampler(tsa):
         assert np.array_equal(sk.Psi_cores[0][0], want)
 
 
+def test_stream_sketch_batch_public_entry_point(tsa):
+    """stream_sketch_batch == [stream_sketch(t, ...) with the same DRMs]: TTs of one signature through the batched
+    pass (40 tensors: more than one slice of 32), a mixed list through the per-tensor fallback; argument policy of
+    stream_sketch (rank direction error)."""
+    rng = np.random.default_rng(77)
+    shape = (9, 10, 11, 8)
+    tts = [tsa.TensorTrain(orc.random_tt(shape, 5, rng)) for _ in range(40)]
+    sks, ld, rd = tsa.stream_sketch_batch(tts, 4, 7, seed=5, return_drm=True)
+    assert len(sks) == 40 and type(ld).__name__ == "TensorTrainDRM"
+    for k in (0, 1, 31, 32, 39):
+        one = tsa.stream_sketch(tts[k], ld.rank, tuple(rd.rank[::-1]), left_drm=ld, right_drm=rd)
+        for a, b in zip(sks[k].Psi_cores + sks[k].Omega_mats, one.Psi_cores + one.Omega_mats):
+            assert a.shape == b.shape and rel(a, b) < TOL
+        assert sks[k].to_tt().error(one.to_tt(), relative=True) < 1e-9
+    mixed = [tts[0], tsa.DenseTensor(tts[1].to_numpy())]
+    ms = tsa.stream_sketch_batch(mixed, ld.rank, tuple(rd.rank[::-1]), left_drm=ld, right_drm=rd)    # explicit DRMs: ranks as tuples (sketch.py:119)
+    for a, b in zip(ms[0].Psi_cores, sks[0].Psi_cores):
+        assert rel(a, b) < 1e-11
+    # (the dense path pairs the right DRM's modes differently -- dense_sketch.py, SURVEY A14 -- so it is compared with itself)
+    alone = tsa.stream_sketch(mixed[1], ld.rank, tuple(rd.rank[::-1]), left_drm=ld, right_drm=rd)
+    for a, b in zip(ms[1].Psi_cores + ms[1].Omega_mats, alone.Psi_cores + alone.Omega_mats):
+        assert rel(a, b) < 1e-13
+    with pytest.raises(ValueError):
+        tsa.stream_sketch_batch(tts[:2], 4, 4)
+    assert tsa.stream_sketch_batch([], 4, 7) == []
+
+
 def _chain_step_case(entry, case, seed_salt=0):
     import ctypes
     from tt_sketch_amd import _native as nat
@@ -1193,6 +1220,33 @@ def test_jacobi_svd_over_the_whole_chip(tsa):
         k = rank or n
         U = us[:, :k] / s[:k]
         assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-10, (m, n)
+
+
+def test_whole_chip_jacobi_with_another_stream_busy(tsa):
+    """VERDICT r2 hygiene / ADVICE: the grid-barrier kernel (cooperative launch) while other library streams hold the
+    chip -- a queue of long products on streams 3 and 5 issued right before; the SVD must come out right (it waits
+    for what is queued, then owns the GPU) and the products too."""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, contract, sync
+    rng = np.random.default_rng(33)
+    P = ctypes.c_void_p
+    m, n = 1200, 1040
+    A = rng.standard_normal((m, n))
+    dA = DevArray.from_host(A)
+    US, S, Vt = DevArray.empty((m, n)), DevArray.empty((n,)), DevArray.empty((n, n))
+    X, Y = DevArray.from_host(rng.standard_normal((3000, 2000))), DevArray.from_host(rng.standard_normal((2000, 3000)))
+    sync()
+    busy = [contract("ij,jk->ik", X, Y, stream=st) for st in (3, 5, 3, 5, 3, 5)]
+    nat.call("ttsk_svd_small", P(dA.ptr), m, n, P(US.ptr), P(S.ptr), P(Vt.ptr), 0)
+    more = [contract("ij,jk->ik", X, Y, stream=3)]
+    sync()
+    want = np.linalg.svd(A, compute_uv=False)
+    assert np.max(np.abs(S.get() - want)) < 1e-12 * want[0]
+    assert rel(US.get() @ Vt.get(), A) < 1e-12
+    ref = X.get() @ Y.get()
+    for b in busy + more:
+        assert rel(b.get(), ref) < 1e-12
 
 
 def test_tt_svd_with_an_unfolding_beyond_one_workgroup(tsa):

@@ -144,6 +144,30 @@ def test_pool_reuse_is_stream_ordered():
         nat._stream_gen[:] = saved[1]
 
 
+def test_helper_stream_of_a_one_call_sketch_is_drained_with_its_caller():
+    """ttsk_tt_sketch* fork stream + 1 and join it back; a blocking read / sync of the CALLER's stream must
+    release buffers tagged with the helper too (they used to wait for a device-wide sync), but not if something else
+    was queued on the helper directly."""
+    from tt_sketch_amd import _native as nat
+    saved = (set(nat._dirty), list(nat._stream_gen), dict(nat._joined_into))
+    try:
+        nat._dirty.clear(); nat._joined_into.clear()
+        nat._mark("ttsk_tt_sketch_batch", (1, 2, 3, 0))          # last argument: stream 0 -> helper 1
+        assert nat._dirty == {0, 1}
+        tag = nat.dirty_snapshot()
+        nat._drained(0)                                          # what ttsk_d2h(..., 0) / ttsk_sync(0) do
+        assert nat._dirty == set() and all(nat.drained_since(s, g) for s, g in tag.items())
+        nat._mark("ttsk_tt_sketch", (0,))
+        nat._mark("ttsk_gemm", (1,))                             # independent work on the helper stream
+        tag = nat.dirty_snapshot()
+        nat._drained(0)
+        assert nat._dirty == {1} and not nat.drained_since(1, tag[1])
+    finally:
+        nat._dirty.clear(); nat._dirty.update(saved[0])
+        nat._stream_gen[:] = saved[1]
+        nat._joined_into.clear(); nat._joined_into.update(saved[2])
+
+
 def _rdv_worker(rank, world, directory, out):
     from tt_sketch_amd.rendezvous import FileRendezvous
     r = FileRendezvous(rank, world, directory=directory, timeout=30)

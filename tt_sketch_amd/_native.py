@@ -167,13 +167,34 @@ def drained_since(stream: int, gen: int) -> bool:
     return _stream_gen[stream] > gen
 
 
+# helper stream -> the stream its work was joined back into (the one-call TT sketches fork stream + 1 and join it
+# before they return): draining the caller's stream then covers the helper too, unless something else was queued on
+# the helper directly in the meantime
+_joined_into = {}
+
+
 def _mark(name, args):
     if name in _STREAM_LAST:
         s = int(args[-1])
         if 0 <= s < NUM_STREAMS:
             _dirty.add(s)
+            _joined_into.pop(s, None)          # direct work on s: it is no longer merely a joined helper
             if name in _TWO_STREAMS:
-                _dirty.add((s + 1) % NUM_STREAMS)
+                h = (s + 1) % NUM_STREAMS
+                if h not in _dirty or _joined_into.get(h) == s:
+                    _joined_into[h] = s
+                _dirty.add(h)
+
+
+def _drained(s):
+    _stream_gen[s] += 1
+    _dirty.discard(s)
+    _joined_into.pop(s, None)
+    for h, into in list(_joined_into.items()):
+        if into == s:                          # everything the helper had in flight was ordered before this drain
+            _stream_gen[h] += 1
+            _dirty.discard(h)
+            del _joined_into[h]
 
 
 def call(name, *args):
@@ -187,11 +208,14 @@ def call(name, *args):
             for i in range(NUM_STREAMS):
                 _stream_gen[i] += 1
             _dirty.clear()
+            _joined_into.clear()
         elif s < NUM_STREAMS:
-            _stream_gen[s] += 1
-            _dirty.discard(s)
+            _drained(s)
     elif name in _BLOCKING:
         s = int(args[-1])
         if 0 <= s < NUM_STREAMS:
-            _stream_gen[s] += 1
-            _dirty.discard(s)
+            _drained(s)
+    elif name == "ttsk_deferred_status":   # waits for its stream
+        s = int(args[0])
+        if 0 <= s < NUM_STREAMS:
+            _drained(s)

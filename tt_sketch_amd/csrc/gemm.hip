@@ -244,7 +244,10 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
             if (trace) fprintf(stderr, "  long-K batch slice %lld: rs = %d\n", (long long)b0, rs);
             if (rs < 0) return rs;
             if (rs == 0) {
-                if (b0 != 0) { set_error("ttsk_gemm: long-K batch covered only in part"); return TTSK_ERR_UNSUPPORTED; }
+                // rejected (a slice's alignment / extent differs from the first ones'): the slices done so far stand, the
+                // rest go through the generic tiles below -- same result in both accumulate modes
+                A += b0 * d.a_b; B += b0 * d.b_b; C += b0 * d.c_b;
+                d.batch -= b0;
                 done = false;
             }
         }

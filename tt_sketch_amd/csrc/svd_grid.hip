@@ -248,12 +248,32 @@ int svd_jacobi_grid(const double *A, int64_t m, int64_t n, double *US, double *S
     static hipEvent_t last = nullptr;
     if (!last) TTSK_HIP(hipEventCreateWithFlags(&last, hipEventDisableTiming));
     else TTSK_HIP(hipStreamWaitEvent(st, last, 0));
+    // ... and whatever the OTHER library streams have queued so far is drained first: the barrier needs every
+    // workgroup resident, compute units held by a neighbour's kernel would make it wait
+    static hipEvent_t busy[TTSK_NUM_STREAMS] = {};
+    for (int i = 0; i < TTSK_NUM_STREAMS; ++i) {
+        hipStream_t other = stream_of(i);
+        if (!other || other == st) continue;
+        if (!busy[i]) TTSK_HIP(hipEventCreateWithFlags(&busy[i], hipEventDisableTiming));
+        TTSK_HIP(hipEventRecord(busy[i], other));
+        TTSK_HIP(hipStreamWaitEvent(st, busy[i], 0));
+    }
     TTSK_HIP(hipMemsetAsync(ctl, 0, sizeof(GridCtl), st));
     hipLaunchKernelGGL(svd_grid_load_kernel, dim3((unsigned)cdiv(n, 32), (unsigned)cdiv(m, 32)), dim3(256), 0, st, A, (int)m,
                        (int)n, W, V);
     TTSK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, W, V, (int)m, (int)n, ctl, sig2, 60);
-    TTSK_LAUNCH_CHECK();
+    {
+        // cooperative launch: the runtime checks that the whole grid can be resident at once and refuses otherwise
+        int mi = (int)m, ni = (int)n, sweeps = 60;
+        void *kargs[] = {(void *)&W, (void *)&V, (void *)&mi, (void *)&ni, (void *)&ctl, (void *)&sig2, (void *)&sweeps};
+        const hipError_t ce = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(256), kargs, 0, st);
+        if (ce != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("svd: cooperative launch of the whole-chip Jacobi kernel refused (%s; grid %d): it needs every workgroup "
+                      "resident, i.e. the GPU to itself", hipGetErrorString(ce), grid);
+            return TTSK_ERR_HIP;
+        }
+    }
     TTSK_HIP(hipEventRecord(last, st));
     std::vector<double> h((size_t)n);
     GridCtl hc;
@@ -261,7 +281,9 @@ int svd_jacobi_grid(const double *A, int64_t m, int64_t n, double *US, double *S
     TTSK_HIP(hipMemcpyAsync(&hc, ctl, sizeof(GridCtl), hipMemcpyDeviceToHost, st));
     TTSK_HIP(hipStreamSynchronize(st));
     if (hc.abort_) {
-        set_error("svd: the grid barrier of the Jacobi kernel timed out (grid %d, %lld x %lld)", grid, (long long)m, (long long)n);
+        set_error("svd: the grid barrier of the Jacobi kernel timed out (grid %d, %lld x %lld): the kernel needs all its workgroups "
+                  "resident at once -- another process on this GPU, or kernels queued on other streams after this one, held "
+                  "compute units (single-tenant requirement)", grid, (long long)m, (long long)n);
         return TTSK_ERR_HIP;
     }
     std::vector<int> order((size_t)n);

@@ -98,12 +98,9 @@ def orthogonal_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank,
     return (sketched, left_drm, right_drm) if return_drm else sketched
 
 
-def stream_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank, seed: Optional[int] = None,
-                  left_drm_type: Optional[Type[DRM]] = None,
-                  right_drm_type: Optional[Type[DRM]] = None, left_drm: Optional[DRM] = None,
-                  right_drm: Optional[DRM] = None, return_drm: bool = False):
-    """Streaming two-sided sketch; returns a ``SketchedTensorTrain`` (reference sketch.py:154-229).
-    One side's ranks must dominate the other's elementwise; only the smaller side is trimmed."""
+def _stream_drms(tensor: Tensor, left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm):
+    """argument policy of ``stream_sketch`` (reference sketch.py:170-219): rank direction, trimming of the smaller side
+    only, default DRM types and seeds, rank checks of explicit DRMs"""
     d = len(tensor.shape)
     lr, rr = np.array(left_rank), np.array(right_rank)
     left_bigger, right_bigger = bool(np.all(lr > rr)), bool(np.all(lr < rr))
@@ -124,9 +121,60 @@ def stream_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank, seed: O
     elif tuple(right_drm.rank[::-1]) != right_rank:
         raise ValueError(
             f"Right rank {right_rank} does not match the rank of the DRM {right_drm.rank}.")
+    return left_drm, right_drm
+
+
+def stream_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank, seed: Optional[int] = None,
+                  left_drm_type: Optional[Type[DRM]] = None,
+                  right_drm_type: Optional[Type[DRM]] = None, left_drm: Optional[DRM] = None,
+                  right_drm: Optional[DRM] = None, return_drm: bool = False):
+    """Streaming two-sided sketch; returns a ``SketchedTensorTrain`` (reference sketch.py:154-229).
+    One side's ranks must dominate the other's elementwise; only the smaller side is trimmed."""
+    left_drm, right_drm = _stream_drms(tensor, left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm)
     sketch = general_sketch(tensor, left_drm, right_drm, method=SketchMethod.streaming)
     sketched = SketchedTensorTrain(sketch, left_drm, right_drm)
     return (sketched, left_drm, right_drm) if return_drm else sketched
+
+
+def stream_sketch_batch(tensors: Sequence[Tensor], left_rank: TTRank, right_rank: TTRank, seed: Optional[int] = None,
+                        left_drm_type: Optional[Type[DRM]] = None, right_drm_type: Optional[Type[DRM]] = None,
+                        left_drm: Optional[DRM] = None, right_drm: Optional[DRM] = None, return_drm: bool = False):
+    """``[stream_sketch(t, ...) for t in tensors]`` with ONE pair of DRMs -- the streaming setting of the reference
+    (sketch.py:292-301: further tensors are sketched with the DRMs of the first) -- as one batched pass on the device
+    where the inputs allow it: TensorTrains of one signature (mode sizes, TT ranks) with TensorTrainDRMs go through
+    ``ttsk_tt_sketch_batch`` in slices of 32 tensors (every chain product is one launch over the whole slice; the DRM
+    cores are read once per launch), anything else falls back to one ``stream_sketch`` per tensor.  Returns the list of
+    ``SketchedTensorTrain`` (device-resident; the sketches of a batched pass share one packed buffer)."""
+    tensors = list(tensors)
+    if not tensors:
+        return ([], left_drm, right_drm) if return_drm else []
+    left_drm, right_drm = _stream_drms(tensors[0], left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm)
+    from . import tt_fused
+    batched = (type(left_drm) is TensorTrainDRM and type(right_drm) is TensorTrainDRM and not left_drm.transpose
+               and right_drm.transpose and all(type(t) is TensorTrain for t in tensors)
+               and all(tuple(t.shape) == tuple(tensors[0].shape) and tuple(t.rank) == tuple(tensors[0].rank) for t in tensors))
+    out = []
+    if batched:
+        import ctypes
+        if tuple(left_drm.shape) != tuple(tensors[0].shape) or tuple(right_drm.shape) != tuple(tensors[0].shape):
+            raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensors[0].shape}")
+        plan = tt_fused.TTSketchPlan(tensors[0].shape, tensors[0].rank, left_drm, right_drm)
+        stride = plan.size + (plan.size & 1)
+        buf = DevArray.empty((len(tensors) * stride,))
+        keep, flat = [], []
+        for t in tensors:
+            ptrs, k = plan.core_pointers(t)
+            keep.append(k)
+            flat += [ptrs[i] for i in range(plan.d)]
+        plan.run_batch((ctypes.c_void_p * len(flat))(*flat), len(tensors), buf, stride)
+        for b in range(len(tensors)):
+            Psi, Om = plan.views(buf[b * stride:b * stride + plan.size])
+            out.append(SketchedTensorTrain(SketchContainer(Psi, Om), left_drm, right_drm))
+    else:
+        lrank, rrank = left_drm.rank, tuple(right_drm.rank[::-1])
+        for t in tensors:
+            out.append(stream_sketch(t, lrank, rrank, left_drm=left_drm, right_drm=right_drm))
+    return (out, left_drm, right_drm) if return_drm else out
 
 
 class SketchedTensorTrain(Tensor):
