@@ -233,6 +233,10 @@ int ttsk_sparse_psi(const double *dev_val, const int64_t *dev_idx_row, const int
  * sparse_gaussian_drm.py:29-44 + sparse_sketch.py:8-69 as one pass per mode over a resident, mode-ordered stream. */
 /* multipliers of the Fortran-order flat index of fast_lazy_gaussian.pyx:60-71 incl. its 32-bit running product (host) */
 int ttsk_sparse_flat_mult(const uint64_t *shape, int m, uint64_t *mult_out);
+/* order of one mode's stream: ascending (index of physical row mode_row, flat index of the suffix rows r_rows as in
+ * ttsk_sparse_mode_stream); the suffix as the secondary key makes the rows of a right-hand DRM table ascend inside a slice */
+int ttsk_sparse_mode_order(const int64_t *dev_idx, int64_t row_stride, size_t N, const int *r_rows, const uint64_t *r_shape, int r_m,
+                           int mode_row, int64_t n, int64_t *dev_perm, int stream);
 /* stream of one mode: record pos = nonzero perm[pos] (perm: ttsk_sparse_sort_mode; NULL = identity): flat index of the
  * l_m index rows l_rows (prefix, shape l_shape) and of the r_m rows r_rows (suffix as the transposed tensor walks it),
  * the index of physical row mode_row as int32, the entry.  Rows are physical rows of the (d, N) index matrix. */

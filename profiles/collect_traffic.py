@@ -1,39 +1,61 @@
-"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only)
-into profiles/r02_traffic.json (or the file named as third argument): HBM bytes per launch for every contraction-kernel instantiation.
+"""Turn rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) into a traffic table:
+HBM bytes per launch for every kernel instantiation, and (optionally) per step of a whole configuration.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch2 -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --inflight 1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write2 -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --inflight 1
-    python profiles/collect_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extra --inflight 1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -o p --output-format csv -- python3 bench.py ... (same command)
+    python profiles/collect_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r03_traffic.json [--total c4_sketch 7]
 
-Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB-like units of
-1024 bytes as rocprofv3 reports them; on gfx950 FETCH_SIZE counts half of the bytes of wide
-(16 B/lane) streaming reads, so it is doubled; WRITE_SIZE is exact for 16-byte streaming stores.
-The 8-byte-per-lane accesses of the non-vector paths are uncalibrated (guide); the table is
-therefore an estimate for kernels that use them.
+`--total NAME STEPS`: also the sum over ALL dispatches of the run divided by STEPS sketches (warm-up included in STEPS),
+stored under NAME -- the counter traffic of one sketch of a configuration that is many small kernels.
+Entries are merged into an existing output file.
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB-like units of 1024 bytes as rocprofv3
+reports them; on gfx950 FETCH_SIZE counts half of the bytes of wide (16 B/lane) streaming reads, so it is doubled;
+WRITE_SIZE is exact for 16-byte streaming stores.  The 8-byte-per-lane accesses of the non-vector paths are
+uncalibrated (guide); the table is therefore an estimate for kernels that use them.
 """
 import json
-import re
+import os
 import sys
 
 import pandas as pd
 
+NAMES = (r"((?:gemm_f64_kernel|skinny_s_kernel|skinny_r_kernel|chain_step_kernel|chain_wide_kernel|stream_small_kernel|"
+         r"sample_rows_kernel|sample_kernel|sparse_psi_mfma_kernel)<[^>]*>|splitk_reduce_kernel|skinny_r_reduce2?|small_gemm_kernel|"
+         r"sg_pass_kernel|sg_psi_reduce_kernel|sg_om_reduce_kernel|expand_rows_kernel|chol_inv_kernel|hh_sign_scale_kernel)")
 
-def per_kernel(path, counter):
+
+def load(path, counter):
     c = pd.read_csv(f"{path}/p_counter_collection.csv")
-    c = c[c.Counter_Name == counter]
-    c["kern"] = c.Kernel_Name.str.extract(
-        r"((?:gemm_f64_kernel|skinny_s_kernel|skinny_r_kernel|chain_step_kernel|stream_small_kernel)<[^>]*>|splitk_reduce_kernel|skinny_r_reduce|small_gemm_kernel)")
-    per_dispatch = c.groupby(["kern", "Dispatch_Id"]).Counter_Value.sum()
+    c = c[c.Counter_Name == counter].copy()
+    c["kern"] = c.Kernel_Name.str.extract(NAMES)
+    return c
+
+
+def per_kernel(c):
+    per_dispatch = c.dropna(subset=["kern"]).groupby(["kern", "Dispatch_Id"]).Counter_Value.sum()
     return per_dispatch.groupby("kern").agg(["median", "max", "count"])
 
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
+args = sys.argv[1:]
+total = None
+if "--total" in args:
+    i = args.index("--total")
+    total = (args[i + 1], float(args[i + 2]))
+    args = args[:i] + args[i + 3:]
+fetch_c, write_c = load(args[0], "FETCH_SIZE"), load(args[1], "WRITE_SIZE")
+fetch, write = per_kernel(fetch_c), per_kernel(write_c)
+dst = args[2] if len(args) > 2 else "profiles/r03_traffic.json"
+out = json.load(open(dst)) if os.path.exists(dst) else {}
 for k in fetch.index:
-    # the biggest dispatches of an instantiation are the batched chain steps (the class the bench reports)
+    # the biggest dispatches of an instantiation are the batched launches (the class the bench reports)
     f = float(fetch.loc[k, "max"]) * 1024 * 2
     w = float(write.loc[k, "max"]) * 1024 if k in write.index else 0.0
     out[k] = dict(fetch_bytes=f, write_bytes=w, bytes_per_launch=f + w, launches_sampled=int(fetch.loc[k, "count"]))
-json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+if total:
+    f = float(fetch_c.Counter_Value.sum()) * 1024 * 2 / total[1]
+    w = float(write_c.Counter_Value.sum()) * 1024 / total[1]
+    out[total[0]] = dict(fetch_bytes=f, write_bytes=w, bytes_per_launch=f + w, sketches=total[1],
+                         note="sum over every dispatch of the run / sketches (set-up kernels of the run included)")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps({k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in out.items()}, indent=1))

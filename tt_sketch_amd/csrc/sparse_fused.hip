@@ -21,6 +21,7 @@
 //   * NO atomics: a wave stores the slices that lie inside its stretch, its first and last (shared) slices go to
 //     per-wave partial blocks that a second kernel adds in wave order -- the sketch is bit-reproducible.
 #include <cstdlib>
+#include <hipcub/hipcub.hpp>
 #include "sampler_dev.h"
 
 namespace ttsk {
@@ -296,6 +297,19 @@ __global__ void sg_stream_kernel(const int64_t *__restrict__ idx, IndexMap lm, I
     }
 }
 
+// sort key of the mode order: (mode index, low 40 bits of the suffix flat index) -- slices in ascending order and,
+// inside a slice, the nonzeros in the order of the suffix they share: the rows of a right-hand DRM table are then
+// visited in ascending order within every slice (each line fetched once per slice instead of once per nonzero)
+__global__ void sg_key_kernel(const int64_t *__restrict__ idx, IndexMap rm, int64_t mode_off, size_t N, uint64_t *__restrict__ keys,
+                              int64_t *__restrict__ iota)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N; e += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t suffix = rm.m ? flat_index(idx, rm, e) : 0;
+        keys[e] = ((uint64_t)idx[mode_off + (int64_t)e] << 40) | (suffix & ((1ull << 40) - 1));
+        iota[e] = (int64_t)e;
+    }
+}
+
 }  // namespace ttsk
 
 using namespace ttsk;
@@ -309,6 +323,36 @@ int ttsk_sparse_flat_mult(const uint64_t *shape, int m, uint64_t *mult_out)
     int rc = make_index_map(shape, m, 0, nullptr, &im);
     if (rc) return rc;
     for (int i = 0; i < m; ++i) mult_out[i] = im.mult[i];
+    return TTSK_OK;
+}
+
+// perm: the nonzeros in ascending (mode index, suffix flat index) order.  The radix sort is the library's
+// (hipcub::DeviceRadixSort, stable): once per tensor and mode, off the per-sketch path.
+int ttsk_sparse_mode_order(const int64_t *dev_idx, int64_t row_stride, size_t N, const int *r_rows, const uint64_t *r_shape, int r_m,
+                           int mode_row, int64_t n, int64_t *dev_perm, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_idx && dev_perm && r_m >= 0 && mode_row >= 0 && n >= 1, "ttsk_sparse_mode_order: bad argument");
+    TTSK_ARG(N < (1ull << 31), "ttsk_sparse_mode_order: more than 2^31 nonzeros");
+    if (N == 0) return TTSK_OK;
+    IndexMap rm{};
+    int rc;
+    if (r_m && (rc = make_index_map(r_shape, r_m, row_stride, r_rows, &rm))) return rc;
+    int bits = 1;
+    while ((1ll << bits) < n && bits < 23) ++bits;
+    size_t temp_bytes = 0;
+    TTSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                (const int64_t *)nullptr, (int64_t *)nullptr, (int)N, 0, 40 + bits, st));
+    char *ws = (char *)scratch(stream, SCRATCH_MISC, 3 * N * 8 + temp_bytes + 256);
+    if (!ws) return TTSK_ERR_HIP;
+    uint64_t *keys = (uint64_t *)ws, *keys_out = keys + N;
+    int64_t *iota = (int64_t *)(keys_out + N);
+    void *temp = ws + 3 * N * 8;
+    size_t blocks = (N + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(sg_key_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dev_idx, rm, (int64_t)mode_row * row_stride, N, keys, iota);
+    TTSK_LAUNCH_CHECK();
+    TTSK_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_out, iota, dev_perm, (int)N, 0, 40 + bits, st));
     return TTSK_OK;
 }
 

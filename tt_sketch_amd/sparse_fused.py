@@ -89,14 +89,18 @@ def _mode_stream(tensor: SparseTensor, mu: int):
     key = ("stream", tuple(order), mu)
     if key not in cache:
         idx, val = tensor.dev_indices(), tensor.dev_entries()
-        perm = tensor.dev_mode_perm(mu)
         l_rows, l_shape = list(order[:mu]), list(tensor.shape[:mu])
         r_rows = [order[d - 1 - i] for i in range(d - 1 - mu)]
         r_shape = [tensor.shape[d - 1 - i] for i in range(d - 1 - mu)]
+        ints = lambda v: (ctypes.c_int * max(len(v), 1))(*v)
+        # mode order with the suffix as the secondary key (not the plain mode sort of dev_mode_perm): inside a slice the
+        # rows of the right-hand DRM tables are then visited in ascending order
+        perm = DevArray.empty((N,), dtype=np.int64)
+        nat.call("ttsk_sparse_mode_order", ctypes.c_void_p(idx.ptr), N, ctypes.c_size_t(N), ints(r_rows), _u64(r_shape or [1]),
+                 len(r_rows), int(order[mu]), int(tensor.shape[mu]), ctypes.c_void_p(perm.ptr), 0)
         fl, fr = DevArray.empty((N,), dtype=np.int64), DevArray.empty((N,), dtype=np.int64)
         jj = DevArray.empty(((N + 1) // 2,), dtype=np.int64)          # int32 records
         vv = DevArray.empty((N,))
-        ints = lambda v: (ctypes.c_int * max(len(v), 1))(*v)
         nat.call("ttsk_sparse_mode_stream", ctypes.c_void_p(idx.ptr), N, ctypes.c_void_p(perm.ptr), ctypes.c_size_t(N),
                  ints(l_rows), _u64(l_shape or [1]), len(l_rows), ints(r_rows), _u64(r_shape or [1]), len(r_rows), int(order[mu]),
                  ctypes.c_void_p(val.ptr), ctypes.c_void_p(fl.ptr), ctypes.c_void_p(fr.ptr), ctypes.c_void_p(jj.ptr),
