@@ -271,43 +271,37 @@ def bench_c3(args, job):
     cs = nat.NUM_STREAMS - 1                        # the one stream every collective goes to, in step order
     P = ctypes.c_void_p
 
-    def reduce_slot(slot, first_stream):
-        """local sum of the rank's sketches, then ONE all-reduce of one sketch"""
+    def allreduce_slot(slot, first_stream):
+        """ONE all-reduce of the rank's partial sketch (already summed over its TTs by ttsk_tt_sketch_sum)"""
         nat.call("ttsk_stream_wait", cs, first_stream)
         if n_mine == 0:
             nat.call("ttsk_memset", P(sums[slot].ptr), 0, ctypes.c_size_t(plan.size * 8), cs)
-        elif plan.size % 2 == 0:
-            nat.call("ttsk_sum_slices", P(sums[slot].ptr), P(outs[slot].ptr), n_mine, ctypes.c_size_t(stride),
-                     ctypes.c_size_t(plan.size), 0, cs)
-        else:
-            for b in range(n_mine):
-                nat.call("ttsk_axpby", P(sums[slot].ptr), P(outs[slot].ptr + 8 * b * stride), 1.0, 1.0 if b else 0.0,
-                         ctypes.c_size_t(plan.size), cs)
         nat.call("ttsk_comm_allreduce_sum", P(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
 
     def step_weak():
         slot = counter[0] % inflight
         counter[0] += 1
-        plan.run_batch(ptr_sets[0], B, outs[slot], stride, stream=2 * slot)      # stream pair (2 slot, 2 slot + 1)
         if comm_on:
-            # both the local sum and the all-reduce overlap the products of step s + 1 on the other stream pair;
-            # this slot's streams touch outs / sums again only after its own all-reduce
-            reduce_slot(slot, 2 * slot)
-            nat.call("ttsk_stream_wait", 2 * slot, cs)
+            # the collective path needs the SUM of the rank's sketches only: chains per TT, Psi / Omega contracted over
+            # (TT, rank) inside the kernels (no per-TT sketch is written, nothing is summed afterwards); the all-reduce
+            # overlaps the products of step s + 1 on the other stream pair
+            plan.run_sum(ptr_sets[0], B, sums[slot], stream=2 * slot)
+            allreduce_slot(slot, 2 * slot)
+            nat.call("ttsk_stream_wait", 2 * slot, cs)      # this slot's streams touch sums again only after its all-reduce
+        else:
+            plan.run_batch(ptr_sets[0], B, outs[slot], stride, stream=2 * slot)      # stream pair (2 slot, 2 slot + 1)
 
     def step_strong():
-        # the whole job: this rank's passes on alternating stream pairs, then sum + all-reduce
-        used = set()
+        # the whole job: this rank's passes, then (collective path) one all-reduce of the rank's partial sketch
+        if comm_on:
+            for i, (b0, cnt) in enumerate(passes):
+                plan.run_sum(ptr_sets[i], cnt, sums[0], accumulate=i > 0, stream=0)     # accumulating: one after the other
+            allreduce_slot(0, 0)
+            nat.call("ttsk_stream_wait", 0, cs)
+            return
         for i, (b0, cnt) in enumerate(passes):
             st = 2 * (i % inflight)
-            used.add(st)
             plan.run_batch(ptr_sets[i], cnt, DevArray(outs[0].buf, b0 * stride, (cnt * stride,), (1,)), stride, stream=st)
-        if comm_on:
-            for st in sorted(used)[1:]:
-                nat.call("ttsk_stream_wait", sorted(used)[0] if used else 0, st)
-            reduce_slot(0, sorted(used)[0] if used else 0)
-            for st in sorted(used) or [0]:
-                nat.call("ttsk_stream_wait", st, cs)       # the next step's passes overwrite outs
 
     step = step_strong if strong else step_weak
     elapsed = job.timed(step, args.steps, args.warmup)
@@ -360,16 +354,17 @@ def bench_c3(args, job):
     if args.check and strong:
         # the sketch of the WHOLE job (sum over every TT of every rank): local sum + one all-reduce, untimed.  The
         # same for every N: what the N = 2 test compares with the N = 1 run.
-        total = DevArray.empty((plan.size + (plan.size & 1),))
-        if n_mine == 0:
-            nat.call("ttsk_memset", P(total.ptr), 0, ctypes.c_size_t(plan.size * 8), 0)
-        else:
-            for b in range(n_mine):
-                nat.call("ttsk_axpby", P(total.ptr), P(outs[0].ptr + 8 * b * stride), 1.0, 1.0 if b else 0.0,
-                         ctypes.c_size_t(plan.size), 0)
         if comm_on:
-            nat.call("ttsk_stream_wait", cs, 0)
-            nat.call("ttsk_comm_allreduce_sum", P(total.ptr), ctypes.c_size_t(plan.size), cs)
+            nat.call("ttsk_sync", -1)
+            total = sums[0]                       # the all-reduced sketch of the last step
+        else:
+            total = DevArray.empty((plan.size + (plan.size & 1),))
+            if n_mine == 0:
+                nat.call("ttsk_memset", P(total.ptr), 0, ctypes.c_size_t(plan.size * 8), 0)
+            else:
+                for b in range(n_mine):
+                    nat.call("ttsk_axpby", P(total.ptr), P(outs[0].ptr + 8 * b * stride), 1.0, 1.0 if b else 0.0,
+                             ctypes.c_size_t(plan.size), 0)
         nat.call("ttsk_sync", -1)
         h = total.get()[:plan.size]
         probe = np.random.default_rng(12345).standard_normal(plan.size)
@@ -444,8 +439,9 @@ def bench_c3(args, job):
                                            "streaming sketch (both chains, Omega, Psi), " +
                                            (f"fixed job of {int(args.items)} TTs dealt over the ranks, {B} per batched pass"
                                             if strong else f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight") +
-                                           ("; the rank's partial sketches are summed and ONE RCCL all-reduce of one sketch per step "
-                                            "gives every rank the sketch of the whole sum" if comm_on else ""),
+                                           ("; collective path: the rank's TTs are sketched as their SUM (ttsk_tt_sketch_sum: chains per TT, "
+                                            "Psi / Omega contracted over (TT, rank) in the kernels) and ONE RCCL all-reduce of one sketch per "
+                                            "step gives every rank the sketch of the whole sum" if comm_on else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, tts_per_step=items_per_step,
                                   steps_in_flight=inflight, single_sketch_latency_ms=single_ms,

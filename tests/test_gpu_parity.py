@@ -623,7 +623,10 @@ def test_sketch_of_a_sum_in_one_call(tsa):
                                      ((150, 160, 150, 140), (30, 32, 28), (26, 24, 22), (28, 30, 34), 3),
                                      ((150, 151, 149), (31, 29), (25, 27), (33, 35), 2),
                                      ((128, 128, 128, 128), (20, 20, 20), (50, 50, 50), (100, 100, 100), 6),
-                                     ((64, 64, 64, 64), (100, 100, 100), (50, 50, 50), (100, 100, 100), 4)]:
+                                     ((64, 64, 64, 64), (100, 100, 100), (50, 50, 50), (100, 100, 100), 4),
+                                     # TT ranks beyond 48: Psi of the sum in one launch, accumulators kept over the terms (stream_small_sum_kernel)
+                                     ((70, 66, 68, 40), (52, 57, 49), (26, 28, 30), (54, 58, 70), 3),
+                                     ((40, 150, 30), (150, 60), (20, 40), (110, 45), 5)]:
         ld, rd = orc.random_tt_drm(shape, lr, False, rng), orc.random_tt_drm(shape, rr, True, rng)
         if len(shape) == 5:
             ld.rank_min, ld.rank_max = (1, 0, 2, 0), (4, 6, 6, 5)

@@ -475,7 +475,19 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                 return t_inter[mu] ? ws0 + offT[mu] + (size_t)(l_lo[mu - 1] * nn) * ldt + (size_t)b * sp
                                    : Tp0(b, mu) + (size_t)(l_lo[mu - 1] * nn) * sp;
             };
-            if (mu < d - 1 && sum && sp > sum_psi_split) {
+            bool psi_summed = false;
+            if (mu < d - 1 && sum && sp > sum_psi_split && !t_inter[mu]) {
+                // Psi_mu of the sum in ONE launch: every wave keeps its tile of the output over all terms (stream_small.h)
+                StreamSmallSumArgs sa{nb, (int)(l * nn), (int)sp, (int)r, Tm(0), ldt, (int64_t)szT[mu], Rm(0), ldr, (int64_t)szR[jr],
+                                      out + psi_at[mu], r, accumulate};
+                g_cls = 4;
+                const int fz = (l * nn < (1ll << 30)) ? stream_small_sum_try(sa, q, stq) : 0;
+                g_cls = NCLS - 1;
+                if (fz < 0) return fz;
+                psi_summed = fz == 1;
+            }
+            if (psi_summed) {
+            } else if (mu < d - 1 && sum && sp > sum_psi_split) {
                 double *blk0 = ws0 + offPs + (size_t)(mu & 1) * blk(nb * szPs);
                 for (int b = 0; b < nb; ++b) { p.A[b] = Tm(b); p.B[b] = Rm(b); p.C[b] = blk0 + (size_t)b * szPs; }
                 StreamSmallArgs ss{nb, (int)(l * nn), (int)sp, (int)r, p.A, ldt, p.B, ldr, p.C, r, 0};
