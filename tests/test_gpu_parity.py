@@ -918,7 +918,8 @@ def test_fused_chain_step_against_einsum(tsa, case):
 
 
 @pytest.mark.parametrize("shape", [(2000, 100, 50), (3000, 60, None), (4000, 290, 145), (2500, 148, 145), (1800, 200, None),
-                                   (300, 256, 256), (700, 130, 129)])
+                                   (300, 256, 256), (700, 130, 129),
+                                   (100, 290, 100), (100, 100, None), (130, 120, 110), (64, 64, None)])   # nearly square: one-workgroup Householder
 def test_orth_step_one_call_and_ranks_beyond_128(tsa, shape):
     """ttsk_orth_step (sketch_dispatch.py:160-174 in one call, verdicts deferred) == scipy lstsq + qr incl. LAPACK's
     column signs; ranks 129..256 through the 2 x 2 block Cholesky (rank 145 / 290 of scripts/plot_timings.py)."""
@@ -952,6 +953,45 @@ def test_orth_step_one_call_and_ranks_beyond_128(tsa, shape):
     if Om is not None:
         from tt_sketch_amd.utils import right_mul_pinv
         assert rel(right_mul_pinv(Psi[:64], Om), orc.right_mul_pinv(Psi[:64], Om)) < 1e-10
+
+
+def test_fast_solves_on_moderately_ill_conditioned_input(tsa):
+    """What the first mode of a sketch with trimmed ranks looks like (Omega_0 = L_0^T R_0 with a SQUARE Gaussian L_0:
+    kappa ~ 1e3..1e4; Psi_0 Omega_0^+ square with kappa ~ 1e5..1e6): the normal-equations pseudo-inverse with its
+    Newton-Schulz step stays accurate and accepted up to kappa = 3e4, the square QR runs on the gate-free Householder
+    kernel -- the deferred flag stays clear and the result equals lstsq + LAPACK QR."""
+    import ctypes
+    import scipy.linalg
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    from tt_sketch_amd.utils import right_mul_pinv
+    rng = np.random.default_rng(44)
+    P = ctypes.c_void_p
+    l, r2, m = 100, 290, 100
+    U, _ = np.linalg.qr(rng.standard_normal((l, l)))
+    V, _ = np.linalg.qr(rng.standard_normal((r2, l)))
+    for kappa in (1e2, 3e3, 2e4):
+        Om = (U * np.logspace(0, -np.log10(kappa), l)) @ V.T
+        Psi = rng.standard_normal((m, r2))
+        got = right_mul_pinv(Psi, Om)
+        want = orc.right_mul_pinv(Psi, Om)
+        assert rel(got, want) < 1e-9, (kappa, rel(got, want))
+        dP, dO, dQ = DevArray.from_host(Psi), DevArray.from_host(Om), DevArray.empty((m, l))
+        nat.call("ttsk_orth_step", P(dP.ptr), m, r2, P(dO.ptr), l, P(dQ.ptr), 0)
+        flag = ctypes.c_int(7)
+        nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+        assert flag.value == 0, kappa
+        Q, _ = scipy.linalg.qr(want, mode="economic")
+        q = dQ.get()
+        assert np.linalg.norm(q.T @ q - np.eye(l)) < 1e-12
+        assert rel(q, Q) < 1e-7 * max(1.0, kappa / 1e2), (kappa, rel(q, Q))          # Q of an ill-conditioned matrix moves with kappa eps
+    # beyond the gate: flagged, and the blocking entry point falls back to the Jacobi SVD
+    Om = (U * np.logspace(0, -7, l)) @ V.T
+    dO = DevArray.from_host(Om)
+    nat.call("ttsk_orth_step", P(dP.ptr), m, r2, P(dO.ptr), l, P(dQ.ptr), 0)
+    nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+    assert flag.value == 1
+    assert rel(right_mul_pinv(Psi, Om), orc.right_mul_pinv(Psi, Om)) < 1e-6
 
 
 def test_orth_step_deferred_flag_on_rank_deficient_input(tsa):

@@ -14,6 +14,7 @@
 namespace ttsk {
 
 constexpr int CHOL_MAX_N = 256;
+constexpr size_t SMALL_QR_MAX = 19000;      // doubles of LDS the one-workgroup Householder QR may take (152 KB)
 
 // sum over the 16 lanes of a DPP row, result in every lane: x += ror(x, 8), 4, 2, 1 (v_mov_dpp row_ror)
 template <int CTRL>
@@ -669,6 +670,64 @@ __global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__rest
     for (int e = tid; e < n * n; e += 256) Rinv[e] *= S[e % n];
 }
 
+// Thin QR of a SMALL, nearly square matrix (m n doubles fit the LDS: the first mode of a sketch whose rank was trimmed to
+// the mode size, m = n_0 rows) in one workgroup: Householder with LAPACK's dlarfg signs, Q formed in place as dorg2r does
+// -- no condition gate (CholeskyQR2 gives up beyond kappa ~ 1e6, which a square unfolding Psi_0 Omega_0^+ reaches
+// easily).  A (m, n) row-major in, Q (m, n) row-major out.  Column-major working copy; every 16-lane group applies a
+// reflector to its own columns.
+__global__ __launch_bounds__(1024) void small_qr_kernel(double *__restrict__ A, int m, int n)
+{
+    extern __shared__ double sq[];
+    double *W = sq;                    // m x n column-major
+    double *tau = sq + (size_t)m * n;  // n
+    const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15, ngrp = 64;
+    for (int e = tid; e < m * n; e += 1024) W[(size_t)(e % n) * m + e / n] = A[e];
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        double *cj = W + (size_t)j * m;
+        double sig = 0.0;
+        for (int i = j + 1 + gl; i < m; i += 16) sig = fma(cj[i], cj[i], sig);
+        sig = row_sum16(sig);
+        const double alpha = cj[j];
+        double beta = alpha, t = 0.0, scale = 0.0;
+        if (sig != 0.0) {                                              // LAPACK dlarfg
+            const double nrm = sqrt(alpha * alpha + sig);
+            beta = alpha >= 0 ? -nrm : nrm;
+            t = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        for (int k = j + 1 + grp; k < n; k += ngrp) {
+            double *ck = W + (size_t)k * m;
+            double w = gl == 0 ? ck[j] : 0.0;                          // v[0] = 1
+            for (int i = j + 1 + gl; i < m; i += 16) w = fma(cj[i] * scale, ck[i], w);
+            w = row_sum16(w) * t;
+            if (gl == 0) ck[j] -= w;
+            for (int i = j + 1 + gl; i < m; i += 16) ck[i] = fma(-w, cj[i] * scale, ck[i]);
+        }
+        __syncthreads();
+        for (int i = j + 1 + tid; i < m; i += 1024) cj[i] *= scale;    // v below the diagonal (v[0] = 1 implied); R is not kept
+        if (tid == 0) tau[j] = t;
+        __syncthreads();
+    }
+    // Q = H_0 ... H_{n-1} [I; 0] in place (dorg2r): from the last reflector to the first
+    for (int j = n - 1; j >= 0; --j) {
+        double *vj = W + (size_t)j * m;
+        const double t = tau[j];
+        for (int k = j + 1 + grp; k < n; k += ngrp) {                  // columns > j already hold columns of Q (zero above row j + 1)
+            double *qk = W + (size_t)k * m;
+            double w = 0.0;                                            // row j of column k is still zero
+            for (int i = j + 1 + gl; i < m; i += 16) w = fma(vj[i], qk[i], w);
+            w = row_sum16(w) * t;
+            if (gl == 0) qk[j] = -w;
+            for (int i = j + 1 + gl; i < m; i += 16) qk[i] = fma(-w, vj[i], qk[i]);
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) vj[i] = i < j ? 0.0 : (i == j ? 1.0 - t : -t * vj[i]);
+        __syncthreads();
+    }
+    for (int e = tid; e < m * n; e += 1024) A[e] = W[(size_t)(e % n) * m + e / n];
+}
+
 // The same signs for n beyond one workgroup's LDS (129..256): the working copy is B itself in global memory (L2), one
 // column per step, 1024 threads.  Only the signs are needed, so the trailing update uses the unscaled columns.
 __global__ __launch_bounds__(1024) void hh_sign_scale_global_kernel(double *__restrict__ B, int n, int square, double *__restrict__ Rinv)
@@ -715,6 +774,11 @@ static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *
                        sticky, pminmax);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
+}
+
+__global__ void add_diag_kernel(double *E, int n, double v)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) E[(size_t)i * n + i] += v;
 }
 
 static int gemm_ex(int64_t M, int64_t N, int64_t K, const double *A, int64_t a_m, int64_t a_k, const double *B, int64_t b_k,
@@ -815,7 +879,7 @@ static int *deferred_flag(int stream)
     return p ? p + stream : nullptr;
 }
 
-static size_t pinv_ws_elems(int n) { return (size_t)3 * n * n + 16 + chol_ws_elems(n); }
+static size_t pinv_ws_elems(int n, int64_t mx) { return (size_t)3 * n * n + 16 + chol_ws_elems(n) + (size_t)mx * n; }   // mx = max(l, r)
 
 // 1 = attempt queued, 0 = not applicable, < 0 = error.  ws_in: pinv_ws_elems(n) doubles of the caller's, or nullptr
 // (then from the stream's arena).  sticky: deferred mode -- no copy of the verdict to the host, the rejection is
@@ -827,23 +891,43 @@ static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double
     int *hs = pinv_host_status();
     int *status = pinv_dev_status(stream);
     if (n > CHOL_MAX || !hs || !status) return 0;
-    double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, pinv_ws_elems(n) * 8);
+    const int64_t mx = l > r ? l : r;
+    double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, pinv_ws_elems(n, mx) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *G = ws, *Rinv = ws + n * n, *Ginv = ws + 2 * n * n, *cws = ws + 3 * n * n + 16;
+    double *x1 = cws + chol_ws_elems(n);        // r x l: the refined pseudo-inverse before it replaces the first one
     int rc;
     if (l <= r) rc = small_gemm(l, l, r, omega, r, 1, omega, 1, r, G, stream);          // Omega Omega^T
     else        rc = small_gemm(r, r, l, omega, 1, r, omega, r, 1, G, stream);          // Omega^T Omega
     if (rc) return rc;
-    // normal equations square the condition number: accept kappa(Omega) up to ~300 (error ~1e-11)
-    rc = chol_inv_any(G, n, Rinv, Ginv, status, 1.0 / 300.0, stream, st, n > CHOL_ONE ? cws : nullptr, sticky);
+    // normal equations square the condition number (error kappa^2 eps); the Newton-Schulz step below brings that back to
+    // ~kappa eps, so kappa(Omega) up to 3e4 is accepted (error <= ~1e-11 either way)
+    rc = chol_inv_any(G, n, Rinv, Ginv, status, 1.0 / 3.0e4, stream, st, n > CHOL_ONE ? cws : nullptr, sticky);
     if (rc) return rc;
     if (!sticky) {
         hs[stream] = 1;
         TTSK_HIP(hipMemcpyAsync(hs + stream, status, sizeof(int), hipMemcpyDeviceToHost, st));
     }
-    if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // Omega^T G^-1
-    else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // G^-1 Omega^T
-    return rc ? rc : 1;
+    if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // X0 = Omega^T G^-1
+    else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // X0 = G^-1 Omega^T
+    if (rc) return rc;
+    // One Newton-Schulz step squares the residual of the normal-equations inverse (kappa^2 eps -> ~kappa eps) and keeps
+    // the minimum-norm property (X stays in the row / column space of Omega): X1 = X0 (2 I - Omega X0)  (l <= r) or
+    // (2 I - X0 Omega) X0.  With it the acceptance gate above can sit at kappa ~ 1e5 instead of 300.
+    double *E = G;                      // n x n, free again
+    if (l <= r) {
+        if ((rc = gemm_ex(l, l, r, omega, r, 1, pinv, l, 1, E, l, -1.0, 0, stream))) return rc;          // E = -Omega X0
+        hipLaunchKernelGGL(add_diag_kernel, dim3(1), dim3(256), 0, st, E, (int)l, 2.0);                  // E = 2 I - Omega X0
+        TTSK_LAUNCH_CHECK();
+        if ((rc = gemm_ex(r, l, l, pinv, l, 1, E, l, 1, x1, l, 1.0, 0, stream))) return rc;               // X1 = X0 E
+    } else {
+        if ((rc = gemm_ex(r, r, l, pinv, l, 1, omega, r, 1, E, r, -1.0, 0, stream))) return rc;          // E = -X0 Omega
+        hipLaunchKernelGGL(add_diag_kernel, dim3(1), dim3(256), 0, st, E, (int)r, 2.0);
+        TTSK_LAUNCH_CHECK();
+        if ((rc = gemm_ex(r, l, r, E, r, 1, pinv, l, 1, x1, l, 1.0, 0, stream))) return rc;               // X1 = E X0
+    }
+    TTSK_HIP(hipMemcpyAsync(pinv, x1, (size_t)r * l * 8, hipMemcpyDeviceToDevice, st));
+    return 1;
 }
 // 1 = accepted (pinv is final), 0 = rejected
 static int pinv_cholesky_verdict(int64_t l, int64_t r, int stream, hipStream_t st)
@@ -864,6 +948,17 @@ static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_
 {
     const int n = (int)n64;
     if (n > CHOL_MAX || m < n) return 0;
+    if (m < 2 * n64 && (size_t)m * n + n <= SMALL_QR_MAX) {
+        // nearly square and small: Householder in one workgroup, no gate to fail
+        static bool attr = false;
+        if (!attr) {
+            TTSK_HIP(hipFuncSetAttribute((const void *)small_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(small_qr_kernel, dim3(1), dim3(1024), ((size_t)m * n + n) * 8, st, A, (int)m, n);
+        TTSK_LAUNCH_CHECK();
+        return 1;
+    }
     double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, qr_ws_elems(m, n) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *Q1 = ws, *G = Q1 + (size_t)m * n, *R1 = G + n * n, *R2 = R1 + n * n, *Qtop = R2 + n * n;
@@ -1028,12 +1123,12 @@ int ttsk_orth_step(const double *dev_psi, int64_t m, int64_t r2, const double *d
         set_error("ttsk_orth_step: (%lld x %lld, rank %lld) is outside the fast path", (long long)m, (long long)r2, (long long)k);
         return TTSK_ERR_UNSUPPORTED;
     }
-    const size_t pw = dev_omega ? pinv_ws_elems((int)nmin) + (size_t)r2 * l : 0;
+    const size_t pw = dev_omega ? pinv_ws_elems((int)nmin, l > r2 ? l : r2) + (size_t)r2 * l : 0;
     double *ws = (double *)scratch(stream, SCRATCH_MISC, (pw + qr_ws_elems(m, (int)k)) * 8);
     if (!ws) return TTSK_ERR_HIP;
     int rc;
     if (dev_omega) {
-        double *pinv = ws + pinv_ws_elems((int)nmin);
+        double *pinv = ws + pinv_ws_elems((int)nmin, l > r2 ? l : r2);
         rc = pinv_cholesky_begin(dev_omega, l, r2, pinv, stream, st, ws, sticky);
         if (rc < 0) return rc;
         if (rc == 0) { set_error("ttsk_orth_step: pseudo-inverse outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
