@@ -973,9 +973,8 @@ def test_fast_solves_on_moderately_ill_conditioned_input(tsa):
     for kappa in (1e2, 3e3, 2e4):
         Om = (U * np.logspace(0, -np.log10(kappa), l)) @ V.T
         Psi = rng.standard_normal((m, r2))
-        got = right_mul_pinv(Psi, Om)
         want = orc.right_mul_pinv(Psi, Om)
-        assert rel(got, want) < 1e-9, (kappa, rel(got, want))
+        assert rel(right_mul_pinv(Psi, Om), want) < 1e-9, kappa        # blocking entry point: normal equations or Jacobi, its own gate
         dP, dO, dQ = DevArray.from_host(Psi), DevArray.from_host(Om), DevArray.empty((m, l))
         nat.call("ttsk_orth_step", P(dP.ptr), m, r2, P(dO.ptr), l, P(dQ.ptr), 0)
         flag = ctypes.c_int(7)

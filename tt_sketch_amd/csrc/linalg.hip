@@ -902,7 +902,10 @@ static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double
     if (rc) return rc;
     // normal equations square the condition number (error kappa^2 eps); the Newton-Schulz step below brings that back to
     // ~kappa eps, so kappa(Omega) up to 3e4 is accepted (error <= ~1e-11 either way)
-    rc = chol_inv_any(G, n, Rinv, Ginv, status, 1.0 / 3.0e4, stream, st, n > CHOL_ONE ? cws : nullptr, sticky);
+    // (the refinement only where a rejection is expensive -- the deferred mode of ttsk_orth_step repeats the whole sketch;
+    // ttsk_pinv has the Jacobi kernel queued behind each attempt and keeps the plain gate at kappa = 300)
+    const bool refine = sticky != nullptr;
+    rc = chol_inv_any(G, n, Rinv, Ginv, status, refine ? 1.0 / 3.0e4 : 1.0 / 300.0, stream, st, n > CHOL_ONE ? cws : nullptr, sticky);
     if (rc) return rc;
     if (!sticky) {
         hs[stream] = 1;
@@ -911,6 +914,7 @@ static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double
     if (l <= r) rc = small_gemm(r, l, l, omega, 1, r, Ginv, l, 1, pinv, stream);        // X0 = Omega^T G^-1
     else        rc = small_gemm(r, l, r, Ginv, r, 1, omega, 1, r, pinv, stream);        // X0 = G^-1 Omega^T
     if (rc) return rc;
+    if (!refine) return 1;
     // One Newton-Schulz step squares the residual of the normal-equations inverse (kappa^2 eps -> ~kappa eps) and keeps
     // the minimum-norm property (X stays in the row / column space of Omega): X1 = X0 (2 I - Omega X0)  (l <= r) or
     // (2 I - X0 Omega) X0.  With it the acceptance gate above can sit at kappa ~ 1e5 instead of 300.
