@@ -15,6 +15,9 @@
 // Rows: a wave owns one or TWO 16-row tiles of the output (both use the same W / E fragments: half the LDS
 // reads per matrix instruction); the tiles are dealt so that the four SIMDs of the CU carry equal shares --
 // 150 rows = 10 tiles as 3 + 3 + 2 + 2 -- with the loader wave on the lightest SIMD (table built on the host).
+// Few rows per tensor (TT rank 20 against DRM rank 100: two row tiles): one tensor per workgroup would leave six of
+// eight waves without rows; a workgroup then serves up to seven tensors of the batch at once (one W image per tensor,
+// a wave per tensor with both its tiles) and every E_k it brings into LDS is used by all of them.
 // Odd DRM ranks: the E image is filled in 16-byte units from 8-byte-aligned rows; the unit behind the last
 // column of a row takes the first element of the next slice along (it meets an output column that is never
 // stored), and the one unit that would reach past the end of the core is patched with an 8-byte load.
@@ -42,6 +45,10 @@ struct ChainWide {
     int xcd_map;                 // 1: workgroups of one (slice range, chunk) share an XCD (E_k from one L2)
     int loader;                  // the wave that only feeds E
     signed char tile0[8], tile1[8];   // row tiles of each wave, -1 = none
+    // Few rows per tensor (J <= 64: the rank-20 terms of a sum): a workgroup serves `tpw` tensors at once -- one W image
+    // each (`wimg` doubles apart), wave w works for tensor slot[w] of the group -- and they share every E_k it loads.
+    int tpw, wimg;
+    signed char slot[8];
 };
 
 // One compute wave: MT row tiles (t[0], t[1]).
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void chain_wide_kernel(ChainWide a)
         prob = blockIdx.x / units;
         unit = blockIdx.x - prob * units;
     }
+    const int prob0 = prob * a.tpw;                    // first tensor of this workgroup's group
     const int g = unit / a.nac, ac = unit - g * a.nac;
     const int a0 = ac * a.ac;
     const int cnt = a.A - a0 < a.ac ? a.A - a0 : a.ac;          // columns of W / rows of E this chunk really has
@@ -263,9 +271,11 @@ __global__ __launch_bounds__(512, 2) void chain_wide_kernel(ChainWide a)
     const int KB1 = ((a.K1 + 3) / 4 + UNR - 1) / UNR * UNR;
     const int A2P = a.A2P;
 
-    // ---- stage the chunk of W: Wl[(c >> 1) * 2 AP + 2 col + (c & 1)] = W[c][a0 + col], zero beyond (K1, cnt)
-    {
-        const double *Wp = uniform_ptr(a.W[prob]);
+    // ---- stage the chunk of W (of every tensor of the group): Wl[(c >> 1) * 2 AP + 2 col + (c & 1)] = W[c][a0 + col], zero beyond (K1, cnt)
+    for (int sl = 0; sl < a.tpw; ++sl) {
+        if (prob0 + sl >= a.nb) break;
+        const double *Wp = uniform_ptr(a.W[prob0 + sl]);
+        double *Wd = Wl + (size_t)sl * a.wimg;
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, ((int64_t)(a.K1 - 1) * a.w_c + a.A) * 8);
         const int total = 4 * KB1 * AP;
         constexpr int BATCH = 8;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void chain_wide_kernel(ChainWide a)
             for (int u = 0; u < BATCH; ++u) {
                 const int e = e0 + 512 * u;
                 const int c = e / AP, col = e - c * AP;
-                if (e < total) Wl[(c >> 1) * 2 * AP + 2 * col + (c & 1)] = v[u];
+                if (e < total) Wd[(c >> 1) * 2 * AP + 2 * col + (c & 1)] = v[u];
             }
         }
     }
@@ -341,14 +351,16 @@ __global__ __launch_bounds__(512, 2) void chain_wide_kernel(ChainWide a)
     }
     __syncthreads();                                   // W staged
     const int t0 = a.tile0[w], t1 = a.tile1[w];
-    if (t0 < 0) return;                                // no rows for this wave (a finished wave leaves the barrier count)
+    const int myprob = prob0 + a.slot[w];
+    if (t0 < 0 || myprob >= a.nb) return;              // no rows for this wave (a finished wave leaves the barrier count)
+    const double *Wmine = Wl + (size_t)a.slot[w] * a.wimg;
     if constexpr (MT2) {
         if (t1 >= 0) {
-            cw_compute<NQF, STRQ, NNF, STRN, WT, UNR, 2>(a, Wl, El, prob, unit, a0, cnt, k_beg, k_end, t0, t1);
+            cw_compute<NQF, STRQ, NNF, STRN, WT, UNR, 2>(a, Wmine, El, myprob, unit, a0, cnt, k_beg, k_end, t0, t1);
             return;
         }
     }
-    cw_compute<NQF, STRQ, NNF, STRN, WT, UNR, 1>(a, Wl, El, prob, unit, a0, cnt, k_beg, k_end, t0, -1);
+    cw_compute<NQF, STRQ, NNF, STRN, WT, UNR, 1>(a, Wmine, El, myprob, unit, a0, cnt, k_beg, k_end, t0, -1);
 }
 
 int chain_wide_try(const ChainStepArgs &c, int stream, hipStream_t st, bool force = false);

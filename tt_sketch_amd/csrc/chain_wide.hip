@@ -58,12 +58,26 @@ static int cw_mode()
 
 // Row tiles -> waves.  Wave w sits on SIMD w & 3 (two waves per SIMD); the tiles are dealt so that the SIMDs
 // carry equal shares, SIMD 3 the lightest one: its second wave is the loader.  Returns false if the rows do not fit.
-static bool cw_wave_table(int NT, bool mt2_ok, ChainWide &a, bool &uses_mt2)
+// tpw > 1: `tpw` tensors per workgroup, each with ceil(NT / 2) (or NT) waves of its own, in order.
+static bool cw_wave_table(int NT, bool mt2_ok, int tpw, ChainWide &a, bool &uses_mt2)
 {
     memset(a.tile0, -1, sizeof(a.tile0));
     memset(a.tile1, -1, sizeof(a.tile1));
+    memset(a.slot, 0, sizeof(a.slot));
     a.loader = 7;
     uses_mt2 = false;
+    if (tpw > 1) {
+        const int wpt = mt2_ok ? (NT + 1) / 2 : NT;
+        if (tpw * wpt > 7) return false;
+        int w = 0;
+        for (int sl = 0; sl < tpw; ++sl)
+            for (int t = 0; t < NT; ++w) {
+                a.slot[w] = (signed char)sl;
+                a.tile0[w] = (signed char)t++;
+                if (mt2_ok && t < NT) { a.tile1[w] = (signed char)t++; uses_mt2 = true; }
+            }
+        return true;
+    }
     if (NT <= 7) {
         for (int w = 0; w < NT; ++w) a.tile0[w] = (signed char)w;
         return true;
@@ -86,8 +100,6 @@ int chain_wide_try(const ChainStepArgs &c, int stream, hipStream_t st, bool forc
 {
     const int mode = force ? 2 : cw_mode();
     if (!mode || c.nb < 1 || c.nb > SK_MAXB) return 0;
-    // a short phase A cannot hide the load of E_k (measured on C5 with the first kernel: the two-launch form wins)
-    if (mode == 1 && 2 * c.K1 < c.A) return 0;
     if (c.J < 1 || c.K1 < 1 || c.A < 1 || c.A2 < 1 || c.n < 1) return 0;
     if (((uintptr_t)c.E & 7) || c.x_j < 0 || c.x_k < 0 || c.x_c < 0 || c.w_c < c.A) return 0;
     int nn, sn;
@@ -105,33 +117,48 @@ int chain_wide_try(const ChainStepArgs &c, int stream, hipStream_t st, bool forc
     const int pad25 = (kb + 24) / 25 * 25, pad5 = (kb + 4) / 5 * 5;
     const int unr = pad25 <= pad5 + 1 ? 25 : 5;
     const int KB1 = unr == 25 ? pad25 : pad5;
-    // ---- chunk plan: the fewest chunks of A whose images fit the LDS; two row tiles per wave only with <= 3 chunk tiles
+    // ---- chunk plan: the fewest chunks of A whose images fit the LDS; two row tiles per wave only with <= 3 chunk tiles.
+    // Few rows per tensor (NT <= 3) and a batch: several tensors per workgroup, as many as have waves and LDS.
     bool uses_mt2 = false;
-    int ci = -1, nac = 0;
+    int ci = -1, nac = 0, tpw = 1;
     size_t lds = 0;
     const int cus = cw_num_cu();
+    const bool out_mt2 = nn + (sn ? 1 : 0) <= 7;
     for (int tryn = 1; tryn <= c.A && tryn <= 64 && ci < 0; ++tryn) {
         const int need = (int)((cdiv(c.A, tryn) + 3) / 4 * 4);
         for (int i = 0; i < 7 && ci < 0; ++i) {
             const int ap = 16 * CW_NQ[i] + 4 * CW_SQ[i];
             if (ap < need) continue;
-            const bool mt2_ok = CW_NQ[i] <= 3 && nn + (sn ? 1 : 0) <= 7;
-            if (!cw_wave_table(NT, mt2_ok, a, uses_mt2)) { if (ap >= 64) break; continue; }
-            const int64_t wl = (int64_t)4 * KB1 * ap;
-            const int ebase = (int)((wl + 1) & ~(int64_t)1);
+            const bool mt2_ok = CW_NQ[i] <= 3 && out_mt2;
+            int want = 1;
+            if (c.nb >= 2 && NT <= 3) {
+                want = 7 / (mt2_ok ? (NT + 1) / 2 : NT);
+                if (want > c.nb) want = c.nb;
+                if (want < 1) want = 1;
+            }
+            const int64_t wimg = ((int64_t)4 * KB1 * ap + 1) & ~(int64_t)1;
             const int64_t units = (int64_t)2 * (ap / 4) * a.A2P;
             const int eunits = (int)cdiv(units, 64) * 64;
             if (eunits / 64 > CF_MAX_DMA) break;
+            // tensors per workgroup: as many as fit beside ONE E image (two images if they fit as well)
+            while (want > 1 && ((size_t)want * wimg + (size_t)eunits * 2) * 8 > 160 * 1024) --want;
+            if (!cw_wave_table(NT, mt2_ok, want, a, uses_mt2)) { if (ap >= 64) break; continue; }
+            const int ebase = (int)((int64_t)want * wimg);
             const size_t one = ((size_t)ebase + (size_t)eunits * 2) * 8, two = ((size_t)ebase + (size_t)eunits * 4) * 8;
             if (one > 160 * 1024) break;               // larger structures only need more: more chunks
-            ci = i; nac = tryn;
-            a.ac = need; a.ebase = ebase; a.eunits = eunits;
+            ci = i; nac = tryn; tpw = want;
+            a.ac = need; a.ebase = ebase; a.eunits = eunits; a.wimg = (int)wimg;
             a.ebuf2 = two <= 160 * 1024 ? 1 : 0;
             lds = a.ebuf2 ? two : one;
         }
     }
     if (ci < 0) return 0;
-    if (!cw_wave_table(NT, CW_NQ[ci] <= 3 && nn + (sn ? 1 : 0) <= 7, a, uses_mt2)) return 0;
+    // TT rank much smaller than the DRM rank (C5: 20 against 50 / 100): the two-launch form merges the rows of ALL tensors
+    // of the batch into one long-K product (no 20 -> 32 row padding) and wins -- measured per right step: 81 us against 101 us
+    // with seven tensors per workgroup here (128 us with one); TTSK_CHAIN_WIDE=2 takes this kernel anyway
+    if (mode == 1 && 2 * c.K1 < c.A) return 0;
+    if (!cw_wave_table(NT, CW_NQ[ci] <= 3 && out_mt2, tpw, a, uses_mt2)) return 0;
+    a.tpw = tpw;
     a.nac = nac;
     // 32-bit byte offsets: the X walk (incl. the prefetch one slice past the end) and T
     if ((c.x_extent + c.x_k + ((int64_t)KB1 * 4 + 32) * c.x_c) * 8 >= (1ll << 32) - 64) return 0;
@@ -139,7 +166,8 @@ int chain_wide_try(const ChainStepArgs &c, int stream, hipStream_t st, bool forc
     a.t_extent = (int64_t)c.A * c.n * c.J;
     if (wt && (a.t_extent + (int64_t)80 * c.n * c.J) * 8 >= (1ll << 32) - 64) return 0;
     // geometry: one workgroup per CU, each a contiguous range of slices of one chunk
-    int wpp = cus / (c.nb * nac) > 0 ? cus / (c.nb * nac) : 1;
+    const int ng = (c.nb + tpw - 1) / tpw;            // workgroup groups of tensors
+    int wpp = cus / (ng * nac) > 0 ? cus / (ng * nac) : 1;
     if (wpp > c.n) wpp = c.n;
     a.wpp = wpp;
     const int units = wpp * nac;
@@ -160,7 +188,7 @@ int chain_wide_try(const ChainStepArgs &c, int stream, hipStream_t st, bool forc
                  (CW_NQ[ci] <= 3 && nn + (sn ? 1 : 0) <= 7) ? "true" : "false");
         prof_open_named(st, -2, 2.0 * c.nb * (double)c.n * c.J * ((double)c.K1 * c.A + (double)c.A * c.A2), name);
     }
-    int rc = launch_chain_wide(ci, a, nn, sn, wt, unr, lds, (int)nslab, st);
+    int rc = launch_chain_wide(ci, a, nn, sn, wt, unr, lds, ng * units, st);
     if (rc == TTSK_OK) {
         ReduceOut ro{};
         for (int b = 0; b < c.nb; ++b) ro.C[b] = c.Out[b];
