@@ -119,16 +119,19 @@ def test_pool_reuse_is_stream_ordered():
     may still be touching it has been drained (cross-stream reuse)."""
     from tt_sketch_amd import device
     saved = (set(nat._dirty), list(nat._stream_gen))
+    saved_join = dict(nat._joined_into)
     try:
         nat._dirty.clear()
+        nat._joined_into.clear()
         nat._mark("ttsk_axpby", (None, None, 1.0, 1.0, 0, 0))        # work on stream 0 only
         tag0 = nat.dirty_snapshot()
         assert set(tag0) == {0}
         assert device._reusable(tag0, 0) and not device._reusable(tag0, 3)
         nat._mark("ttsk_gemm", (None, None, None, None, None, 3))    # a multi-stream region opens
-        nat._mark("ttsk_tt_sketch", (None,) * 14 + (4,))             # forks a helper on stream 5
+        nat._mark("ttsk_tt_sketch", (None,) * 14 + (4,))             # forks a helper on stream 5, joined back into 4
+        assert nat._dirty >= {0, 3, 4, 5}
         tag = nat.dirty_snapshot()
-        assert set(tag) == {0, 3, 4, 5}
+        assert set(tag) == {0, 3, 4}                                 # the joined helper counts as its caller's stream
         assert not any(device._reusable(tag, s) for s in range(nat.NUM_STREAMS))
         nat._stream_gen[3] += 1                                      # as ttsk_sync(3) does
         nat._dirty.discard(3)
@@ -142,6 +145,8 @@ def test_pool_reuse_is_stream_ordered():
         nat._dirty.clear()
         nat._dirty.update(saved[0])
         nat._stream_gen[:] = saved[1]
+        nat._joined_into.clear()
+        nat._joined_into.update(saved_join)
 
 
 def test_helper_stream_of_a_one_call_sketch_is_drained_with_its_caller():

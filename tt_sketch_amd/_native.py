@@ -160,8 +160,15 @@ def sync_epoch() -> int:
 
 
 def dirty_snapshot() -> dict:
-    """{stream: drain generation} of every stream with work queued since its last drain."""
-    return {s: _stream_gen[s] for s in _dirty}
+    """{stream: drain generation} of every stream with work queued since its last drain.  A helper stream whose work
+    was joined back into its caller's stream (the one-call TT sketches) counts as that stream: whatever is queued there
+    later is ordered behind the helper's work too, so a buffer released now may go straight to a user on the caller's
+    stream (every temporary of a loop of one-call sketches used to miss the pool and cost a hipMalloc)."""
+    out = {}
+    for s in _dirty:
+        t = _joined_into.get(s, s)
+        out[t] = _stream_gen[t]
+    return out
 
 
 def drained_since(stream: int, gen: int) -> bool:

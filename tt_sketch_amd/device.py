@@ -43,6 +43,13 @@ _pool: "dict[int, list]" = {}   # size class -> [(tag, ptr), ...], most recently
 _pool_bytes = {True: 0, False: 0}     # large / small
 
 
+def _prod(shape) -> int:
+    n = 1
+    for x in shape:
+        n *= int(x)
+    return n
+
+
 def _size_class(nbytes: int) -> int:
     if nbytes >= _POOL_MIN:
         return (int(nbytes) + (2 << 20) - 1) & ~((2 << 20) - 1)
@@ -151,7 +158,7 @@ class DevArray:
     def empty(cls, shape, dtype=_F64, stream=0) -> "DevArray":
         """``stream``: the library stream that touches the array first (see the pool note above)."""
         shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
-        n = int(np.prod(shape, dtype=np.int64))
+        n = _prod(shape)
         return cls(_Buffer(n * np.dtype(dtype).itemsize, stream), 0, shape, _c_strides(shape), dtype)
 
     @classmethod
@@ -183,7 +190,7 @@ class DevArray:
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return _prod(self.shape)
 
     def is_contiguous(self) -> bool:
         exp = 1
@@ -218,9 +225,9 @@ class DevArray:
         shape = list(int(s) for s in shape)
         if -1 in shape:
             k = shape.index(-1)
-            rest = int(np.prod([s for i, s in enumerate(shape) if i != k], dtype=np.int64))
+            rest = _prod([s for i, s in enumerate(shape) if i != k])
             shape[k] = self.size // rest if rest else 0
-        if int(np.prod(shape, dtype=np.int64)) != self.size:
+        if _prod(shape) != self.size:
             raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
         st = _view_strides(self.shape, self.strides, shape)
         if st is None:
@@ -306,7 +313,7 @@ def _view_strides(shape, strides, new_shape) -> Optional[Tuple[int, ...]]:
     """Strides of a reshape that needs no copy, or None (NumPy's no-copy rule)."""
     old = [(n, s) for n, s in zip(shape, strides) if n != 1]
     new_strides = [0] * len(new_shape)
-    if int(np.prod(new_shape, dtype=np.int64)) == 0:
+    if _prod(new_shape) == 0:
         return _c_strides(new_shape)
     oi = 0
     ni = 0

@@ -53,6 +53,7 @@ class TTSketchPlan:
         self.left_rank = tuple(left_drm.rank)
         self.right_rank = tuple(right_drm.rank[::-1])
         self.size = int(nat.lib().ttsk_tt_sketch_size(d, self.n, self.l_lo, self.l_hi, self.r_lo, self.r_hi))
+        self._layout = None
 
     def new_buffer(self) -> DevArray:
         return DevArray.empty((self.size,))
@@ -84,21 +85,25 @@ class TTSketchPlan:
                  1 if accumulate else 0, stream)
 
     def views(self, out: DevArray) -> Tuple[List[DevArray], List[DevArray]]:
-        """Psi / Omega arrays as views into the packed buffer."""
-        d, off = self.d, 0
-        lr, rr = (1,) + self.left_rank, self.right_rank + (1,)
-        Psi, Om = [], []
-        for mu in range(d):
-            shp = (lr[mu], self.shape[mu], rr[mu])
-            size = int(np.prod(shp))
-            Psi.append(out[off:off + size].reshape(shp))
-            off += size
-        for mu in range(d - 1):
-            shp = (self.left_rank[mu], self.right_rank[mu])
-            size = shp[0] * shp[1]
-            Om.append(out[off:off + size].reshape(shp))
-            off += size
-        return Psi, Om
+        """Psi / Omega arrays as views into the packed (contiguous) buffer."""
+        d = self.d
+        if self._layout is None:
+            lr, rr = (1,) + self.left_rank, self.right_rank + (1,)
+            shapes = [(lr[mu], self.shape[mu], rr[mu]) for mu in range(d)] + \
+                     [(self.left_rank[mu], self.right_rank[mu]) for mu in range(d - 1)]
+            off, lay = 0, []
+            for shp in shapes:
+                st, acc = [], 1
+                for n in reversed(shp):
+                    st.append(acc)
+                    acc *= n
+                lay.append((off, shp, tuple(reversed(st))))
+                off += acc
+            self._layout = lay
+        if out.strides != (1,):
+            out = out.contiguous()
+        arrs = [DevArray(out.buf, out.offset + off, shp, st) for off, shp, st in self._layout]
+        return arrs[:d], arrs[d:]
 
 
 def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list, list]]:
