@@ -299,6 +299,14 @@ int ttsk_qr_thin(double *dev_A, int64_t m, int64_t n, int stream);
  * ttsk_qr_thin.  TTSK_ERR_UNSUPPORTED outside the fast path (ranks > 256, TTSK_FAST_SOLVES=0). */
 int ttsk_orth_step(const double *dev_psi, int64_t m, int64_t r2, const double *dev_omega, int64_t l, double *dev_q,
                    int stream);
+/* The same in two pieces for orthogonal_sketch, whose d - 1 Omega are all known before its sequential loop over the modes
+ * starts: the pseudo-inverses of `count` matrices of ONE shape (l, r) with every stage as one batched launch (fast path
+ * as in ttsk_orth_step, min(l, r) <= 128, verdicts in `stream`'s deferred flag), then per mode Q = qr_thin(Psi_mat P)
+ * with P (r2, l) given. */
+int ttsk_pinv_batch_deferred(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs,
+                             int stream);
+int ttsk_orth_step_pinv(const double *dev_psi, int64_t m, int64_t r2, const double *dev_pinv, int64_t l, double *dev_q,
+                        int stream);
 /* *host_flag = 1 if a factorisation queued by ttsk_orth_step on `stream` was rejected since the last call; waits for
  * the stream and clears the flag. */
 int ttsk_deferred_status(int stream, int *host_flag);

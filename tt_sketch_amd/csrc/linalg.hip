@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include "common.h"
+#include "skinny.h"
 
 namespace ttsk {
 
@@ -472,6 +473,11 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
 {
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
+    // a batch of independent factorisations: workgroup b takes the matrices n * n * b further on (grid 1: the plain call)
+    G += (size_t)blockIdx.x * n * n;
+    Rinv += (size_t)blockIdx.x * n * n;
+    if (Ginv) Ginv += (size_t)blockIdx.x * n * n;
+    status += blockIdx.x;
     double *A = sm;
     double *xd = sm + n * ld;
     for (int e = tid; e < n * n; e += 256) A[(e / n) * ld + e % n] = G[e];
@@ -762,7 +768,7 @@ static int small_gemm(int64_t M, int64_t N, int64_t K, const double *A, int64_t 
 }
 
 static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st,
-                       int *sticky = nullptr, double *pminmax = nullptr)
+                       int *sticky = nullptr, double *pminmax = nullptr, int count = 1)
 {
     static bool attr = false;
     if (!attr) {
@@ -770,14 +776,15 @@ static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *
         TTSK_HIP(hipFuncSetAttribute((const void *)hh_sign_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status, cond_tol,
-                       sticky, pminmax);
+    hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)count), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status,
+                       cond_tol, sticky, pminmax);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
 
 __global__ void add_diag_kernel(double *E, int n, double v)
 {
+    E += (size_t)blockIdx.x * n * n;               // batch: one n x n matrix per workgroup
     for (int i = threadIdx.x; i < n; i += blockDim.x) E[(size_t)i * n + i] += v;
 }
 
@@ -1143,6 +1150,83 @@ int ttsk_orth_step(const double *dev_psi, int64_t m, int64_t r2, const double *d
     rc = qr_cholesky(dev_q, m, k, stream, st, ws + pw, sticky);
     if (rc < 0) return rc;
     if (rc == 0) { set_error("ttsk_orth_step: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+    return TTSK_OK;
+}
+
+// The pseudo-inverses of `count` matrices of ONE shape, fast path + Newton-Schulz step, every stage as ONE batched
+// launch (7 launches for the d - 1 Omega of an orthogonal sketch instead of 7 each); verdicts deferred to `stream`'s flag.
+int ttsk_pinv_batch_deferred(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(count >= 1 && count <= SK_MAXB && dev_omegas && dev_pinvs && l >= 1 && r >= 1, "ttsk_pinv_batch_deferred: bad argument");
+    int *sticky = deferred_flag(stream);
+    const int n = (int)(l < r ? l : r);
+    if (!fast_solves() || !sticky || n > CHOL_ONE || pinv_rcond(l, r, -1.0) > 1e-4) {
+        set_error("ttsk_pinv_batch_deferred: (%lld x %lld) is outside the batched fast path", (long long)l, (long long)r);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    const size_t per = (size_t)3 * n * n + (size_t)r * l;
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, ((size_t)count * per + 64) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *G0 = ws, *R0 = G0 + (size_t)count * n * n, *I0 = R0 + (size_t)count * n * n, *X0 = I0 + (size_t)count * n * n;
+    int *status = (int *)(X0 + (size_t)count * r * l);
+    const double *Om[SK_MAXB], *cG[SK_MAXB], *cI[SK_MAXB], *cX[SK_MAXB];
+    double *G[SK_MAXB], *X[SK_MAXB], *P[SK_MAXB];
+    for (int b = 0; b < count; ++b) {
+        TTSK_ARG(dev_omegas[b] && dev_pinvs[b], "ttsk_pinv_batch_deferred: NULL matrix %d", b);
+        Om[b] = dev_omegas[b]; P[b] = dev_pinvs[b];
+        G[b] = G0 + (size_t)b * n * n; cG[b] = G[b];
+        cI[b] = I0 + (size_t)b * n * n;
+        X[b] = X0 + (size_t)b * r * l; cX[b] = X[b];
+    }
+    auto desc = [](int64_t M, int64_t N, int64_t K, int64_t a_m, int64_t a_k, int64_t b_k, int64_t b_n, double alpha) {
+        ttsk_gemm_desc d{};
+        d.batch = 1; d.M = M; d.N = N; d.Ko = 1; d.Ki = K;
+        d.a_m = a_m; d.a_ki = a_k; d.b_ki = b_k; d.b_n = b_n; d.c_m = N; d.c_n = 1;
+        d.alpha = alpha;
+        return d;
+    };
+    int rc;
+#define TTSK_PB(call) do { rc = (call); if (rc < 0) return rc; if (rc == 0) { set_error("ttsk_pinv_batch_deferred: product outside the small kernel"); return TTSK_ERR_UNSUPPORTED; } } while (0)
+    if (l <= r) {
+        TTSK_PB(small_try_batch(desc(l, l, r, r, 1, 1, r, 1.0), count, Om, Om, G, stream, st));                  // G = Omega Omega^T
+        if ((rc = launch_chol(G0, n, R0, I0, status, 1.0 / 3.0e4, st, sticky, nullptr, count))) return rc;
+        TTSK_PB(small_try_batch(desc(r, l, l, 1, r, l, 1, 1.0), count, Om, cI, X, stream, st));                  // X0 = Omega^T G^-1
+        TTSK_PB(small_try_batch(desc(l, l, r, r, 1, l, 1, -1.0), count, Om, cX, G, stream, st));                 // E = -Omega X0
+        hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)count), dim3(256), 0, st, G0, n, 2.0);                // E = 2 I - Omega X0
+        TTSK_LAUNCH_CHECK();
+        TTSK_PB(small_try_batch(desc(r, l, l, l, 1, l, 1, 1.0), count, cX, cG, P, stream, st));                  // X1 = X0 E
+    } else {
+        TTSK_PB(small_try_batch(desc(r, r, l, 1, r, r, 1, 1.0), count, Om, Om, G, stream, st));                  // G = Omega^T Omega
+        if ((rc = launch_chol(G0, n, R0, I0, status, 1.0 / 3.0e4, st, sticky, nullptr, count))) return rc;
+        TTSK_PB(small_try_batch(desc(r, l, r, r, 1, 1, r, 1.0), count, cI, Om, X, stream, st));                  // X0 = G^-1 Omega^T
+        TTSK_PB(small_try_batch(desc(r, r, l, l, 1, r, 1, -1.0), count, cX, Om, G, stream, st));                 // E = -X0 Omega
+        hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)count), dim3(256), 0, st, G0, n, 2.0);
+        TTSK_LAUNCH_CHECK();
+        TTSK_PB(small_try_batch(desc(r, l, r, r, 1, l, 1, 1.0), count, cG, cX, P, stream, st));                  // X1 = E X0
+    }
+#undef TTSK_PB
+    return TTSK_OK;
+}
+
+// ttsk_orth_step with the pseudo-inverse already made (ttsk_pinv_batch_deferred): Q = qr_thin(Psi_mat P), P (r2, l)
+int ttsk_orth_step_pinv(const double *dev_psi, int64_t m, int64_t r2, const double *dev_pinv, int64_t l, double *dev_q, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(dev_psi && dev_pinv && dev_q && m >= 1 && r2 >= 1 && l >= 1, "ttsk_orth_step_pinv: bad argument");
+    TTSK_ARG(m >= l, "ttsk_orth_step_pinv: cannot orthogonalise a %lld x %lld unfolding", (long long)m, (long long)l);
+    int *sticky = deferred_flag(stream);
+    if (!fast_solves() || !sticky || l > CHOL_MAX) {
+        set_error("ttsk_orth_step_pinv: rank %lld is outside the fast path", (long long)l);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    double *ws = (double *)scratch(stream, SCRATCH_DRIVER, qr_ws_elems(m, (int)l) * 8);      // (the pinvs may live in SCRATCH_MISC)
+    if (!ws) return TTSK_ERR_HIP;
+    int rc;
+    if ((rc = small_gemm(m, l, r2, dev_psi, r2, 1, dev_pinv, l, 1, dev_q, stream))) return rc;      // M = Psi_mat Omega^+
+    rc = qr_cholesky(dev_q, m, l, stream, st, ws, sticky);
+    if (rc < 0) return rc;
+    if (rc == 0) { set_error("ttsk_orth_step_pinv: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
     return TTSK_OK;
 }
 

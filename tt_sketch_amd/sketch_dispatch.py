@@ -104,7 +104,30 @@ def get_sketch_method(tensor: Tensor, drm: DRM) -> Callable:
     raise ValueError(f"DRM of type {type(drm)} can't sketch {type(tensor)}")
 
 
-def orth_step(Psi, Omega=None, deferred: bool = False) -> DevArray:
+def _pinvs_up_front(Omega_mats) -> dict:
+    """{mu: pinv(Omega_mu)} for the Omega of shapes that occur at least twice, every stage ONE batched launch
+    (``ttsk_pinv_batch_deferred``): all Omega are known before the sequential Psi loop starts.  Verdicts deferred."""
+    groups = {}
+    for mu, Om in enumerate(Omega_mats):
+        O = as_dev(Om).contiguous()
+        groups.setdefault(tuple(O.shape), []).append((mu, O))
+    out = {}
+    for (l, r), items in groups.items():
+        if len(items) < 2 or min(l, r) > 128 or len(items) > 32:
+            continue
+        Ps = [DevArray.empty((r, l)) for _ in items]
+        P = ctypes.c_void_p
+        try:
+            nat.call("ttsk_pinv_batch_deferred", len(items), (P * len(items))(*[O.ptr for _, O in items]), l, r,
+                     (P * len(items))(*[p.ptr for p in Ps]), 0)
+        except nat.TtskUnsupported:
+            continue
+        for (mu, O), p in zip(items, Ps):
+            out[mu] = (p, O)
+    return out
+
+
+def orth_step(Psi, Omega=None, deferred: bool = False, pinv=None) -> DevArray:
     """Psi <- Q of thin QR(Psi_mat pinv(Omega)) (reference :160-174), all on the device.
 
     ``deferred``: one library call (``ttsk_orth_step``) that does not wait for the acceptance tests of its
@@ -115,6 +138,10 @@ def orth_step(Psi, Omega=None, deferred: bool = False) -> DevArray:
     k = r2 if Omega is None else int(as_dev(Omega).shape[0])
     if r1 * n < k:
         raise ValueError(f"cannot orthogonalise a {r1 * n} x {k} unfolding: trim the sketch ranks")
+    if deferred and pinv is not None:
+        Q = DevArray.empty((r1 * n, k))
+        nat.call("ttsk_orth_step_pinv", ctypes.c_void_p(M.ptr), r1 * n, r2, ctypes.c_void_p(pinv[0].ptr), k, ctypes.c_void_p(Q.ptr), 0)
+        return Q.reshape(r1, n, k)
     if deferred:
         Om = None if Omega is None else as_dev(Omega).contiguous()
         Q = DevArray.empty((r1 * n, k))
@@ -207,6 +234,7 @@ def _sketch_pass(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM, method
     orthogonalise = method in (SketchMethod.hmt, SketchMethod.orthogonal)
     if orthogonalise:
         left_psi_drm = OrthogTTDRM(left_rank, tensor)
+    pinvs = _pinvs_up_front(Omega_mats) if (deferred and method == SketchMethod.orthogonal) else {}
 
     Psi_cores: List[DevArray] = []
     psi_method = PSI_METHODS[type(tensor)]
@@ -228,7 +256,7 @@ def _sketch_pass(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM, method
                          psi_shape=(r1, tensor.shape[mu], r2))
         if mu < d - 1:
             if method == SketchMethod.orthogonal:
-                Psi = orth_step(Psi, Omega_mats[mu], deferred)
+                Psi = orth_step(Psi, Omega_mats[mu], deferred, pinvs.get(mu))
             elif method == SketchMethod.hmt:
                 Psi = orth_step(Psi, None, deferred)
         Psi_cores.append(as_dev(Psi))
