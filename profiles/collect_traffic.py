@@ -3,11 +3,13 @@ HBM bytes per launch for every kernel instantiation, and (optionally) per step o
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extra --inflight 1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -o p --output-format csv -- python3 bench.py ... (same command)
-    python profiles/collect_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r03_traffic.json [--total c4_sketch 7]
+    python profiles/collect_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r03_traffic.json [--total c4_sketch 11 [--only 'sg_']]
 
-`--total NAME STEPS`: also the sum over ALL dispatches of the run divided by STEPS sketches (warm-up included in STEPS),
-stored under NAME -- the counter traffic of one sketch of a configuration that is many small kernels.
-Entries are merged into an existing output file.
+`--total NAME STEPS`: also the sum over the dispatches of the run (with `--only REGEX`: of the kernels whose name matches,
+i.e. without the one-time set-up of the run: sorts, stream building, table sampling) divided by STEPS sketches (warm-up
+included in STEPS), stored under NAME -- the counter traffic of one sketch of a configuration that is many kernels.
+Entries are merged into an existing output file; a kernel that is already there keeps its entry (the headline run is
+collected first: its batched launches are the ones the bench reports).
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB-like units of 1024 bytes as rocprofv3
 reports them; on gfx950 FETCH_SIZE counts half of the bytes of wide (16 B/lane) streaming reads, so it is doubled;
@@ -38,7 +40,11 @@ def per_kernel(c):
 
 
 args = sys.argv[1:]
-total = None
+total, only = None, None
+if "--only" in args:
+    i = args.index("--only")
+    only = args[i + 1]
+    args = args[:i] + args[i + 2:]
 if "--total" in args:
     i = args.index("--total")
     total = (args[i + 1], float(args[i + 2]))
@@ -48,14 +54,19 @@ fetch, write = per_kernel(fetch_c), per_kernel(write_c)
 dst = args[2] if len(args) > 2 else "profiles/r03_traffic.json"
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 for k in fetch.index:
+    if k in out:
+        continue
     # the biggest dispatches of an instantiation are the batched launches (the class the bench reports)
     f = float(fetch.loc[k, "max"]) * 1024 * 2
     w = float(write.loc[k, "max"]) * 1024 if k in write.index else 0.0
     out[k] = dict(fetch_bytes=f, write_bytes=w, bytes_per_launch=f + w, launches_sampled=int(fetch.loc[k, "count"]))
 if total:
-    f = float(fetch_c.Counter_Value.sum()) * 1024 * 2 / total[1]
-    w = float(write_c.Counter_Value.sum()) * 1024 / total[1]
+    fc = fetch_c[fetch_c.Kernel_Name.str.contains(only)] if only else fetch_c
+    wc = write_c[write_c.Kernel_Name.str.contains(only)] if only else write_c
+    f = float(fc.Counter_Value.sum()) * 1024 * 2 / total[1]
+    w = float(wc.Counter_Value.sum()) * 1024 / total[1]
     out[total[0]] = dict(fetch_bytes=f, write_bytes=w, bytes_per_launch=f + w, sketches=total[1],
-                         note="sum over every dispatch of the run / sketches (set-up kernels of the run included)")
+                         note=("sum over the dispatches matching %r" % only if only else "sum over every dispatch of the run")
+                              + " / sketches")
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in out.items()}, indent=1))

@@ -28,7 +28,7 @@ python3 profiles/by_grid.py gpurun_out/prof_r03s/bench_kernel_trace.csv gpurun_o
 rm -f gpurun_out/r03_traffic.json
 python3 profiles/collect_traffic.py gpurun_out/pmc_r03f gpurun_out/pmc_r03w gpurun_out/r03_traffic.json > gpurun_out/r03_traffic.txt 2>&1
 python3 profiles/collect_traffic.py gpurun_out/pmc_r03f_c2 gpurun_out/pmc_r03w_c2 gpurun_out/r03_traffic.json --total c2_sketch 7 >> gpurun_out/r03_traffic.txt 2>&1
-python3 profiles/collect_traffic.py gpurun_out/pmc_r03f_c4 gpurun_out/pmc_r03w_c4 gpurun_out/r03_traffic.json --total c4_sketch 11 >> gpurun_out/r03_traffic.txt 2>&1
+python3 profiles/collect_traffic.py gpurun_out/pmc_r03f_c4 gpurun_out/pmc_r03w_c4 gpurun_out/r03_traffic.json --total c4_sketch 11 --only 'sg_pass|sg_psi_reduce|sg_om_reduce|fillBuffer' >> gpurun_out/r03_traffic.txt 2>&1
 python3 profiles/collect_traffic.py gpurun_out/pmc_r03f_ref150 gpurun_out/pmc_r03w_ref150 gpurun_out/r03_traffic.json >> gpurun_out/r03_traffic.txt 2>&1
 python3 profiles/sq_counters.py gpurun_out/pmc_r03sq/p_counter_collection.csv > gpurun_out/r03_sq_counters.txt 2>&1
 cp gpurun_out/prof_r03_full/bench_kernel_stats.csv gpurun_out/r03_bench_full_kernel_stats.csv

@@ -2,6 +2,8 @@
 // pure latency.  One wave per 16 x 32 output tile, operands straight from memory into MFMA
 // registers for the whole K (ring of 8 k-blocks in flight), no LDS and no barrier; up to
 // SK_MAXB problems of one shape (the tensors of a batch, or a uniformly strided batch) per launch.
+// Long contractions (K >= 256: Omega of a sum of 32 terms has K = 640) are cut over the 2 or 4 waves of a
+// workgroup, the partial tiles summed in wave order through LDS (round 3: 25 -> ~10 us per product at C5).
 // tensor_train_sketch.py:8-19 (Omega), tensor_train_drm.py:79-88 (first mode) in the reference.
 #include <cstdlib>
 #include "skinny.h"
@@ -20,9 +22,11 @@ struct SmallG {
 
 constexpr int SG_D = 8;
 
-__global__ __launch_bounds__(64) void small_gemm_kernel(SmallG a)
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallG a)
 {
-    const int lane = threadIdx.x, x16 = lane & 15, kq = lane >> 4;
+    __shared__ double part[3][64][9];                 // partial tiles of waves 1..3 (padded rows)
+    const int lane = threadIdx.x & 63, x16 = lane & 15, kq = lane >> 4;
+    const int ws = threadIdx.x >> 6, nws = blockDim.x >> 6;
     int w = blockIdx.x;
     const int nt = w % a.tiles_n;
     w /= a.tiles_n;
@@ -35,12 +39,15 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SmallG a)
     const uint32_t ob0 = col0 < a.N ? (uint32_t)(((int64_t)col0 * a.b_n + (int64_t)kq * a.b_k) * 8) : OOB_OFF;
     const uint32_t ob1 = col1 < a.N ? (uint32_t)(((int64_t)col1 * a.b_n + (int64_t)kq * a.b_k) * 8) : OOB_OFF;
     const uint32_t sa = (uint32_t)(4 * a.a_k * 8), sb = (uint32_t)(4 * a.b_k * 8);
-    const int nkb_lane = (a.K - kq + 3) >> 2, KB = (a.K + 3) >> 2, ITER = (KB + SG_D - 1) / SG_D;
+    const int nkb_lane = (a.K - kq + 3) >> 2, KB = (a.K + 3) >> 2;
+    // this wave's stretch of the k-blocks
+    const int per = (KB + nws - 1) / nws, kb_beg = ws * per, kb_end = kb_beg + per < KB ? kb_beg + per : KB;
+    const int ITER = kb_end > kb_beg ? (kb_end - kb_beg + SG_D - 1) / SG_D : 0;
 
     double ra_[SG_D], rb0[SG_D], rb1[SG_D];
-    int kb_load = 0;
+    int kb_load = kb_beg;
     auto issue = [&](int d) {
-        const bool ok = kb_load < nkb_lane;
+        const bool ok = kb_load < nkb_lane && kb_load < kb_end;
         ra_[d] = ld8(ra, (ok && oa != OOB_OFF) ? oa + (uint32_t)kb_load * sa : OOB_OFF, 0);
         rb0[d] = ld8(rb, (ok && ob0 != OOB_OFF) ? ob0 + (uint32_t)kb_load * sb : OOB_OFF, 0);
         rb1[d] = ld8(rb, (ok && ob1 != OOB_OFF) ? ob1 + (uint32_t)kb_load * sb : OOB_OFF, 0);
@@ -66,6 +73,21 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SmallG a)
                 acc[1][t] = mfma4(rA[t], b1, acc[1][t]);
             }
         }
+    }
+    if (nws > 1) {                                     // partial tiles meet in wave 0, summed in wave order
+        if (ws > 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) part[ws - 1][lane][4 * q + t] = acc[q][t];
+        }
+        __syncthreads();
+        if (ws > 0) return;
+        for (int o = 1; o < nws; ++o)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[q][t] += part[o - 1][lane][4 * q + t];
     }
     // rotated A: acc[q][t] at lane (i = l>>4, beta = (l>>2)&3, j4 = l&3) is D[4((beta+t)&3) + i][4 beta + j4]
     const int i = lane >> 4, beta = (lane >> 2) & 3, j4 = lane & 3;
@@ -142,7 +164,8 @@ int small_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, con
     g.accumulate = d.accumulate;
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * count * (double)d.M * (double)d.N * (double)K, 5, 0, false, false);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)(count * g.tiles_m * g.tiles_n)), dim3(64), 0, st, g);
+    const int ksplit = K >= 512 ? 4 : (K >= 256 ? 2 : 1);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)(count * g.tiles_m * g.tiles_n)), dim3(64 * ksplit), 0, st, g);
     if (prof) prof_close(st);
     TTSK_LAUNCH_CHECK();
     return 1;
