@@ -15,6 +15,7 @@
 namespace ttsk {
 
 constexpr int CHOL_MAX_N = 256;
+constexpr int CHOL_SIGN_MAX = 72;             // second factorisation + sign reconstruction in one kernel: three n x (n + 1) images in LDS
 constexpr size_t SMALL_QR_MAX = 19000;      // doubles of LDS the one-workgroup Householder QR may take (152 KB)
 
 // sum over the 16 lanes of a DPP row, result in every lane: x += ror(x, 8), 4, 2, 1 (v_mov_dpp row_ror)
@@ -465,11 +466,17 @@ namespace ttsk {
 
 // G (n x n symmetric, row-major) = R^T R; Rinv = R^-1 (upper triangular, dense n x n) and optionally
 // Ginv = Rinv Rinv^T = G^-1.  status[0] = 0 ok, 1 rejected.
+__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid);
+
+// Qtop (optional, n <= CHOL_SIGN_MAX): the call is the SECOND factorisation of CholeskyQR2 -- the kernel goes on to form
+// the top n x n block of Q = Qtop R^-1 in LDS, reconstructs LAPACK's Householder column signs from it (hh_signs_lds)
+// and writes Rinv with its columns scaled by them: three launches of qr_cholesky in one.
 // sticky (optional): set to 1 on rejection, never cleared here (deferred verdicts: ttsk_orth_step);
 // pminmax (optional): smallest / largest pivot, for callers that combine several blocks (chol_inv_any).
 __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
                                                        double *__restrict__ Ginv, int *__restrict__ status,
-                                                       double cond_tol, int *__restrict__ sticky, double *__restrict__ pminmax)
+                                                       double cond_tol, int *__restrict__ sticky, double *__restrict__ pminmax,
+                                                       const double *__restrict__ Qtop = nullptr, int square = 0)
 {
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
@@ -599,6 +606,24 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         if (r >= n || c >= n || r > c) return 0.0;
         return r == c ? xd[c] : A[c * ld + r];
     };
+    if (Qtop) {
+        // top block of Q = Qtop X (X upper triangular), the signs of LAPACK's reflectors from its modified LU, Rinv = X S
+        double *B = xd + n, *S = B + n * ld, *Qs = S + n;      // Qs: Qtop staged (one coalesced pass instead of n dependent loads per cell)
+        for (int e = tid; e < n * n; e += 256) Qs[(e / n) * ld + e % n] = Qtop[e];
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, c = e - i * n;
+            const double *qi = Qs + i * ld, *xc = A + c * ld;    // X[k][c], k < c, sits at A[c][k]; the diagonal in xd
+            double acc = qi[c] * xd[c];
+            for (int k = 0; k < c; ++k) acc = fma(qi[k], xc[k], acc);
+            B[i * ld + c] = acc;
+        }
+        __syncthreads();
+        hh_signs_lds(B, n, ld, square, S, shadow, tid);
+        for (int i = ti; i < n; i += 16)
+            for (int c = tc; c < n; c += 16) Rinv[i * n + c] = Xe(i, c) * S[c];
+        return;
+    }
     for (int i = ti; i < n; i += 16)
         for (int c = tc; c < n; c += 16) Rinv[i * n + c] = Xe(i, c);
     if (Ginv) {
@@ -630,18 +655,11 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
 // the modified LU of the top n x n block of Q (Ballard et al., "Reconstructing Householder vectors
 // from TSQR"): S_j = -sgn(pivot_j); for a square matrix the last reflector is the identity.
 // Scales the columns of Rinv (n x n) by S in place.
-__global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__restrict__ Qtop, int n, int square,
-                                                            double *__restrict__ Rinv)
+__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid)
 {
-    extern __shared__ double sm[];
-    const int ld = n + 1, tid = threadIdx.x;
-    double *B = sm, *S = sm + n * ld;
-    for (int e = tid; e < n * n; e += 256) B[(e / n) * ld + e % n] = Qtop[e];
-    __syncthreads();
     // only the signs are needed: every thread derives the modified pivots itself and the trailing update uses the
     // unscaled columns; two columns per barrier as in chol_inv_kernel (row j + 1 after step j through a shadow row)
     const int ti = tid >> 4, tc = tid & 15;
-    __shared__ double shadow[2 * 128];
     int j = 0;
     for (; j + 1 < n; j += 2) {
         const double *b0 = B + j * ld, *b1 = B + (j + 1) * ld;
@@ -673,6 +691,18 @@ __global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__rest
         if (tid == 0) S[j] = sgn;
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void hh_sign_scale_kernel(const double *__restrict__ Qtop, int n, int square,
+                                                            double *__restrict__ Rinv)
+{
+    extern __shared__ double sm[];
+    const int ld = n + 1, tid = threadIdx.x;
+    double *B = sm, *S = sm + n * ld;
+    __shared__ double shadow[2 * 128];
+    for (int e = tid; e < n * n; e += 256) B[(e / n) * ld + e % n] = Qtop[e];
+    __syncthreads();
+    hh_signs_lds(B, n, ld, square, S, shadow, tid);
     for (int e = tid; e < n * n; e += 256) Rinv[e] *= S[e % n];
 }
 
@@ -980,6 +1010,17 @@ static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_
     if ((rc = chol_inv_any(G, n, R1, nullptr, status, 1e-6, stream, st, cws, sticky))) return rc;       // kappa(A) up to ~1e6
     if ((rc = small_gemm(m, n, n, A, n, 1, R1, n, 1, Q1, stream))) return rc;            // Q1 = A R1^-1
     if ((rc = small_gemm(n, n, m, Q1, 1, n, Q1, n, 1, G, stream))) return rc;            // Q1^T Q1
+    if (n <= CHOL_SIGN_MAX) {
+        // second factorisation (G ~ identity), top block of Q and the sign reconstruction in ONE kernel
+        static bool attr = false;
+        if (!attr) {
+            TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(3 * n * (n + 1) + 2 * n) * 8, st, G, n, R2, (double *)nullptr,
+                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, m == n64 ? 1 : 0);
+        TTSK_LAUNCH_CHECK();
+    } else {
     if ((rc = chol_inv_any(G, n, R2, nullptr, status + 1, 0.5, stream, st, cws, sticky))) return rc;    // must be ~identity
     if ((rc = small_gemm(n, n, n, Q1, n, 1, R2, n, 1, Qtop, stream))) return rc;         // top block of Q
     if (n <= CHOL_ONE) {
@@ -990,6 +1031,7 @@ static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_
         hipLaunchKernelGGL(hh_sign_scale_global_kernel, dim3(1), dim3(1024), 0, st, Qtop, n, m == n64 ? 1 : 0, R2);
     }
     TTSK_LAUNCH_CHECK();
+    }
     if (!sticky) {
         int host_status[2] = {1, 1};
         TTSK_HIP(hipMemcpyAsync(host_status, status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
