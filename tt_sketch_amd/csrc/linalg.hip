@@ -476,7 +476,7 @@ __device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, do
 __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
                                                        double *__restrict__ Ginv, int *__restrict__ status,
                                                        double cond_tol, int *__restrict__ sticky, double *__restrict__ pminmax,
-                                                       const double *__restrict__ Qtop = nullptr, int square = 0)
+                                                       const double *__restrict__ Qtop = nullptr, int square = 0, int expand = 1)
 {
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
@@ -502,6 +502,35 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     auto rcp2 = [](double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); };
     __shared__ double shadow[2 * 128];
     int j = 0;
+    bool expanded = false;
+    if (Qtop && expand) {
+        // The second factorisation of CholeskyQR2 sees G = I + E with |E| ~ n kappa(A)^2 eps.  For n max|E| <= 1e-8 the
+        // factor's inverse is I - Phi(E) (Phi: strict upper triangle + half the diagonal) to within n |E|^2 < 1e-17:
+        // no recurrence at all (n / 2 steps of ~1600 cycles otherwise).
+        double em = 0.0;
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, c = e - i * n;
+            em = fmax(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
+        }
+        em = fmax(em, jac_dpp<0xB1>(em));
+        em = fmax(em, jac_dpp<0x4E>(em));
+        if ((tid & 3) == 0) shadow[tid >> 2] = em;
+        __syncthreads();
+        em = 0.0;
+        for (int k = 0; k < 64; ++k) em = fmax(em, shadow[k]);
+        __syncthreads();
+        if (em * n <= 1e-8) {                                   // NaN compares false: the recurrence below rejects it
+            for (int e = tid; e < n * n; e += 256) {
+                const int i = e / n, c = e - i * n;
+                if (i < c) A[c * ld + i] = -A[i * ld + c];      // X[i][c] lives at A[c][i]
+                else if (i == c) xd[c] = 1.0 - 0.5 * (A[i * ld + i] - 1.0);
+            }
+            if (tid == 0) status[0] = 0;
+            __syncthreads();
+            expanded = true;
+        }
+    }
+    if (!expanded) {
     for (; j + 1 < n; j += 2) {
         const double *r0 = A + j * ld, *r1 = A + (j + 1) * ld;
         double p0 = r0[j];
@@ -600,6 +629,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
             __syncthreads();
         }
     }
+    }   // !expanded
     // X(r, c) from that storage (zero below the diagonal): the results are written straight from it -- no pass that
     // makes X dense in LDS first
     auto Xe = [&](int r, int c) -> double {
@@ -1012,13 +1042,14 @@ static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_
     if ((rc = small_gemm(n, n, m, Q1, 1, n, Q1, n, 1, G, stream))) return rc;            // Q1^T Q1
     if (n <= CHOL_SIGN_MAX) {
         // second factorisation (G ~ identity), top block of Q and the sign reconstruction in ONE kernel
+        static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
         static bool attr = false;
         if (!attr) {
             TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             attr = true;
         }
         hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(3 * n * (n + 1) + 2 * n) * 8, st, G, n, R2, (double *)nullptr,
-                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, m == n64 ? 1 : 0);
+                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, m == n64 ? 1 : 0, chol_expand);
         TTSK_LAUNCH_CHECK();
     } else {
     if ((rc = chol_inv_any(G, n, R2, nullptr, status + 1, 0.5, stream, st, cws, sticky))) return rc;    // must be ~identity
