@@ -310,6 +310,20 @@ int ttsk_orth_step_pinv(const double *dev_psi, int64_t m, int64_t r2, const doub
 /* *host_flag = 1 if a factorisation queued by ttsk_orth_step on `stream` was rejected since the last call; waits for
  * the stream and clears the flag. */
 int ttsk_deferred_status(int stream, int *host_flag);
+/* orthogonal_sketch / hmt_sketch of a tensor train with tensor-train DRMs as ONE call (sketch.py:44-151,
+ * sketch_dispatch.py:160-193, 202-275 with method = orthogonal / hmt; tensor_train_drm.py:71-88 for the chains):
+ * right chain (and, orthogonal, left chain + Omega_mu) on the kernels of ttsk_tt_sketch, the pseudo-inverses batched,
+ * then per mode T = (Q_0 .. Q_{mu-1})^T-chain (x) X_mu, Q_mu = qr_thin(T R_mu Omega_mu^+) (hmt: qr_thin(T R_mu)).
+ *   n, s, X       as ttsk_tt_sketch
+ *   rt, DR        right DRM, true ranks and cores in its walking order (mode d-1 first), rt[0] = 1
+ *   lt, DL        left DRM (lt[0] = 1), or DL == NULL: hmt_sketch
+ *   cores_out[d]  core mu (k_{mu-1}, n[mu], k_mu) with k_mu = lt[mu+1] (orthogonal) or rt[d-1-mu] (hmt), k_{-1} = k_{d-1} = 1
+ *   omega_out     orthogonal: d - 1 matrices (lt[mu+1], rt[d-1-mu])
+ * Verdicts deferred as in ttsk_orth_step (ttsk_deferred_status on `stream` afterwards).  TTSK_ERR_UNSUPPORTED: ranks
+ * beyond 256, k_{mu-1} n[mu] < k_mu, Omega of different shapes or min(l, r) > 128, TTSK_FAST_SOLVES=0. */
+int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
+                        const double *const *X, const double *const *DL, const double *const *DR,
+                        double *const *cores_out, double *const *omega_out, int stream);
 
 /* ---- multi-GPU: one RCCL sum of the packed partial sketch ------------------
  * SketchContainer.__add__ across ranks (sketch_container.py:61-69). */

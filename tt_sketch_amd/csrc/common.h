@@ -12,7 +12,7 @@ void set_error(const char *fmt, ...);
 hipStream_t stream_of(int s);   // nullptr + error set if invalid / not initialised
 int ensure_init();
 // grow-only per-stream arenas; nullptr + error on failure.  Slots keep nested users apart:
-enum { SCRATCH_DRIVER = 0, SCRATCH_GEMM = 1, SCRATCH_MISC = 2, SCRATCH_SLOTS = 3 };
+enum { SCRATCH_DRIVER = 0, SCRATCH_GEMM = 1, SCRATCH_MISC = 2, SCRATCH_ORTH = 3, SCRATCH_SLOTS = 4 };
 void *scratch(int stream, int slot, size_t bytes);
 
 #define TTSK_HIP(call)                                                          \

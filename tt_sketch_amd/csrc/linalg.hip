@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "skinny.h"
+#include "linalg_int.h"
 
 namespace ttsk {
 
@@ -901,7 +902,7 @@ static int chol_inv_any(const double *G, int n, double *Rinv, double *Ginv, int 
     return TTSK_OK;
 }
 
-static bool fast_solves()
+bool fast_solves()
 {
     static int v = [] { const char *e = getenv("TTSK_FAST_SOLVES"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -935,7 +936,7 @@ static int *pinv_dev_status(int stream)
 
 // deferred verdicts (ttsk_orth_step): one sticky word per stream, set by any rejected fast-path factorisation since the
 // last ttsk_deferred_status
-static int *deferred_flag(int stream)
+int *deferred_flag(int stream)
 {
     static int *p = [] {
         int *q = nullptr;
@@ -1011,11 +1012,11 @@ static int pinv_cholesky_verdict(int64_t l, int64_t r, int stream, hipStream_t s
     return host_status ? 0 : 1;
 }
 
-static size_t qr_ws_elems(int64_t m, int n) { return (size_t)m * n + 4 * (size_t)n * n + 16 + chol_ws_elems(n); }
+size_t qr_ws_elems(int64_t m, int n) { return (size_t)m * n + 4 * (size_t)n * n + 16 + chol_ws_elems(n); }
 
 // thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected.  sticky: deferred mode -- the
 // factorisation always runs to the end (A is overwritten either way), a rejection is recorded in *sticky.
-static int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in = nullptr, int *sticky = nullptr)
+int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in, int *sticky)
 {
     const int n = (int)n64;
     if (n > CHOL_MAX || m < n) return 0;

@@ -6,6 +6,7 @@
 #include "skinny.h"
 #include "chain_fused.h"
 #include "chain_wide.h"
+#include "tt_chain.h"
 #include "stream_small.h"
 
 namespace ttsk {
@@ -206,7 +207,7 @@ int ttsk_tt_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt,
 static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
                           const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                           const double *const *X, const double *const *DL, const double *const *DR, double *out,
-                          int64_t out_stride, int accumulate, int stream, bool sum);
+                          int64_t out_stride, int accumulate, int stream, bool sum, ttsk::TTChains *co = nullptr);
 
 int ttsk_tt_sketch_batch(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
                          const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
@@ -231,13 +232,17 @@ int ttsk_tt_sketch_sum(int nb, int d, const int64_t *n, const int64_t *s, const 
 static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *l_lo,
                           const int64_t *l_hi, const int64_t *rt, const int64_t *r_lo, const int64_t *r_hi,
                           const double *const *X, const double *const *DL, const double *const *DR, double *out,
-                          int64_t out_stride, int accumulate, int stream, bool sum)
+                          int64_t out_stride, int accumulate, int stream, bool sum, ttsk::TTChains *co)
 {
+    // co (tt_chain.h): the chains and Omega only -- no Psi, T not kept; the chain matrices stay in the workspace and
+    // their addresses are handed back (the orthogonalising sketches of tt_orth.hip go on from there)
     TTSK_STREAM(st, stream);
     TTSK_ARG(nb >= 1, "ttsk_tt_sketch_batch: need nb >= 1, got %d", nb);
     TTSK_ARG(d >= 2, "ttsk_tt_sketch: need d >= 2, got %d", d);
-    TTSK_ARG(n && s && lt && l_lo && l_hi && rt && r_lo && r_hi && X && DL && DR && out,
+    TTSK_ARG(n && s && lt && l_lo && l_hi && rt && r_lo && r_hi && X && DR && (co ? (DL || !co->want_left) : (DL && out)),
              "ttsk_tt_sketch: NULL argument");
+    TTSK_ARG(!co || (nb == 1 && !sum && !accumulate), "ttsk_tt_sketch: chains-only mode is for one tensor");
+    const bool no_left = co && !co->want_left;
     TTSK_ARG(s[0] == 1 && s[d] == 1 && lt[0] == 1 && rt[0] == 1, "ttsk_tt_sketch: boundary ranks must be 1");
     for (int mu = 0; mu < d - 1; ++mu) {
         TTSK_ARG(0 <= l_lo[mu] && l_lo[mu] <= l_hi[mu] && l_hi[mu] <= lt[mu + 1],
@@ -379,6 +384,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     // left chain: L_mu and the shared products T_mu = L_{mu-1}^T X_mu
     auto left_step = [&](int mu) -> int {
         const int64_t sn = s[mu], sp = s[mu + 1], nn = n[mu];
+        if (no_left || (co && mu == d - 1)) return TTSK_OK;         // (the last step only makes Psi_{d-1})
         BatchPtrs p{};
         if (mu == 0) {
             // L_0[p',q'] = sum_k X_0[0,k,p'] D_0[0,k,q']
@@ -393,7 +399,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             double *Op[SK_MAXB], *Tp[SK_MAXB];
             for (int b = 0; b < nb; ++b) { Wp[b] = Lp(b, mu - 1); Xp[b] = Xc(b, mu); Op[b] = Lp(b, mu); Tp[b] = Tp0(b, mu); }
             ChainStepArgs cs{nb, (int)nn, (int)sn, (int)lfull, (int)lt[mu + 1], (int)sp, Wp, lfull, Xp, 1, sp, nn * sp,
-                             sn * nn * sp, DL[mu], Tp, Op};
+                             sn * nn * sp, DL[mu], co ? nullptr : Tp, Op};
             g_cls = 3;
             int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
             if (fz == 0) fz = chain_wide_try(cs, aux, st_aux);
@@ -565,6 +571,29 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
         CK(left_step(t));
     }
     // both chains are needed from here on, on both streams
+    if (co) {
+        for (int j = 0; j < d - 1; ++j) co->Rc[j] = Rp(0, j);
+        for (int mu = 0; mu < d - 1; ++mu) co->Lc[mu] = no_left ? nullptr : Lp(0, mu);
+        if (no_left) return TTSK_OK;
+        CK(ttsk_stream_wait(stream, aux));   // join
+        // Omega_mu = L_mu^T R_mu: one batched launch when the modes share a shape
+        bool same = true;
+        for (int mu = 1; mu < d - 1; ++mu)
+            same = same && s[mu + 1] == s[1] && lt[mu + 1] == lt[1] && rt[d - 1 - mu] == rt[d - 1];
+        BatchPtrs o{};
+        for (int mu = 0; mu < d - 1; ++mu) { o.A[mu] = Lp(0, mu); o.B[mu] = Rp(0, d - 2 - mu); o.C[mu] = co->omega[mu]; }
+        if (same && d - 1 <= SK_MAXB) {
+            CK(gemm_batch(5, d - 1, desc2(lt[1], rt[d - 1], 1, s[1], 1, 0, lt[1], 0, rt[d - 1], 1, rt[d - 1], 1, 0), o, stream, st));
+        } else {
+            for (int mu = 0; mu < d - 1; ++mu) {
+                BatchPtrs o1{};
+                o1.A[0] = o.A[mu]; o1.B[0] = o.B[mu]; o1.C[0] = o.C[mu];
+                const int64_t l = lt[mu + 1], r = rt[d - 1 - mu];
+                CK(gemm_batch(5, 1, desc2(l, r, 1, s[mu + 1], 1, 0, l, 0, r, 1, r, 1, 0), o1, stream, st));
+            }
+        }
+        return TTSK_OK;
+    }
     CK(ttsk_stream_wait(stream, aux));
     CK(ttsk_stream_wait(aux, stream));
     // Few tensors of one shape in every mode (one C3 tensor: 4 Psi, 5 Omega of equal shapes): the interior Psi
@@ -617,3 +646,21 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
 }
 
 }  // extern "C"
+
+namespace ttsk {
+
+int tt_chains(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt, const double *const *X,
+              const double *const *DL, const double *const *DR, TTChains *out, int stream)
+{
+    if (d < 2 || d > 64 || !out) { set_error("tt_chains: bad argument"); return TTSK_ERR_ARG; }
+    std::vector<int64_t> zero(d, 0), lhi(d, 1), rhi(d, 1), ones(d + 1, 1);
+    for (int mu = 0; mu < d - 1; ++mu) {
+        if (out->want_left) lhi[mu] = lt[mu + 1];
+        rhi[mu] = rt[mu + 1];
+    }
+    return tt_sketch_core(1, d, n, s, out->want_left ? lt : ones.data(), zero.data(), lhi.data(), rt, zero.data(), rhi.data(), X,
+                          DL, DR, nullptr, 0, 0, stream, false, out);
+}
+
+}  // namespace ttsk
+

@@ -1,0 +1,139 @@
+// orthogonal_sketch / hmt_sketch of a tensor train with tensor-train DRMs as ONE call
+// (reference sketch_dispatch.py:160-193, 202-275 with method = orthogonal / hmt; sketch.py:44-151).
+//
+//   1. the right DRM chain, and for `orthogonal` the left chain and Omega_mu = L_mu^T R_mu: the kernels of the
+//      streaming sketch (tt_chains, tt_fused.hip), two streams;
+//   2. orthogonal: the d - 1 pseudo-inverses as batched launches (ttsk_pinv_batch_deferred) and W_mu = R_mu Omega_mu^+
+//      (hmt: W_mu = R_mu);
+//   3. mode by mode: T = Q-chain (x) X_mu,  M = T W_mu  (= Psi_mu Omega_mu^+ without ever forming Psi_mu),
+//      Q_mu = qr(M) by CholeskyQR2 with LAPACK's signs,  next Q-chain = Q_mu^T T  (T is formed once and used twice).
+//
+// Nothing is read back: the verdicts of the fast factorisations accumulate in the stream's deferred flag
+// (ttsk_deferred_status); the caller repeats a rejected sketch on the robust path (ttsk_pinv / ttsk_qr_thin).
+#include <algorithm>
+#include <vector>
+#include "common.h"
+#include "skinny.h"
+#include "tt_chain.h"
+#include "linalg_int.h"
+
+using namespace ttsk;
+
+namespace {
+
+int gemm2(int64_t M, int64_t N, int64_t K, const double *A, int64_t a_m, int64_t a_k, const double *B, int64_t b_k, int64_t b_n,
+          double *C, int stream)
+{
+    ttsk_gemm_desc d{};
+    d.batch = 1; d.M = M; d.N = N; d.Ko = 1; d.Ki = K;
+    d.a_m = a_m; d.a_ki = a_k; d.b_ki = b_k; d.b_n = b_n; d.c_m = N; d.c_n = 1;
+    d.alpha = 1.0;
+    return ttsk_gemm(&d, A, B, C, nullptr, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ttsk_pinv_batch_deferred(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream);
+
+int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
+                        const double *const *X, const double *const *DL, const double *const *DR,
+                        double *const *cores_out, double *const *omega_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(d >= 2 && d <= 64 && n && s && rt && X && DR && cores_out, "ttsk_tt_orth_sketch: bad argument");
+    const bool orth = DL != nullptr;                       // orthogonal: left DRM and Omega; hmt: right DRM only
+    TTSK_ARG(!orth || (lt && omega_out), "ttsk_tt_orth_sketch: the orthogonal method needs lt and omega_out");
+    TTSK_ARG(s[0] == 1 && s[d] == 1 && rt[0] == 1 && (!orth || lt[0] == 1), "ttsk_tt_orth_sketch: boundary ranks must be 1");
+    int *sticky = deferred_flag(stream);
+    auto rr = [&](int mu) { return rt[d - 1 - mu]; };                          // right sketch rank of mode mu < d - 1
+    auto kk = [&](int mu) { return mu < 0 ? (int64_t)1 : (orth ? lt[mu + 1] : rr(mu)); };   // rank of the output cores
+    bool ok = fast_solves() && sticky != nullptr;
+    int64_t mmax = 0, kmax = 0, smax = 0, tmax = 0;
+    for (int mu = 0; mu < d; ++mu) {
+        TTSK_ARG(n[mu] >= 1 && s[mu + 1] >= 1 && X[mu] && cores_out[mu], "ttsk_tt_orth_sketch: bad mode %d", mu);
+        const int64_t m = kk(mu - 1) * n[mu];
+        tmax = std::max(tmax, m * s[mu + 1]);
+        smax = std::max(smax, s[mu + 1]);
+        if (mu == d - 1) break;
+        TTSK_ARG(DR[mu] && rt[mu + 1] >= 1 && (!orth || (DL[mu] && lt[mu + 1] >= 1 && omega_out[mu])), "ttsk_tt_orth_sketch: bad DRM core %d", mu);
+        ok = ok && kk(mu) <= QR_CHOL_MAX_N && m >= kk(mu);
+        if (orth) ok = ok && lt[mu + 1] == lt[1] && rr(mu) == rr(0) && std::min(lt[1], rr(0)) <= 128;   // one batched pinv
+        mmax = std::max(mmax, m);
+        kmax = std::max(kmax, kk(mu));
+    }
+    if (!ok || d - 1 > SK_MAXB) {
+        set_error("ttsk_tt_orth_sketch: outside the one-call path (ranks, shapes or TTSK_FAST_SOLVES=0)");
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    int rc;
+#define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
+    // ---- 1. chains (and Omega)
+    TTChains ch{};
+    ch.want_left = orth ? 1 : 0;
+    ch.omega = omega_out;
+    CK(tt_chains(d, n, s, lt, rt, X, DL, DR, &ch, stream));
+    // ---- workspace of this driver
+    auto blk = [](size_t v) { return (v + 31) & ~(size_t)31; };
+    const size_t szP = orth ? blk((size_t)rr(0) * lt[1]) : 0, szW = orth ? blk((size_t)smax * lt[1]) : 0;
+    const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax), szQ = blk(qr_ws_elems(mmax, (int)kmax));
+    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW) + 2 * szL + szT + szQ) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *P0 = ws, *W0 = P0 + (size_t)(d - 1) * szP, *Lb = W0 + (size_t)(d - 1) * szW, *T = Lb + 2 * szL, *qws = T + szT;
+    // ---- 2. W_mu = R_mu Omega_mu^+  (s[mu+1] x l)
+    std::vector<const double *> W(d - 1);
+    if (orth) {
+        const double *om[SK_MAXB];
+        double *pv[SK_MAXB];
+        for (int mu = 0; mu < d - 1; ++mu) { om[mu] = omega_out[mu]; pv[mu] = P0 + (size_t)mu * szP; }
+        CK(ttsk_pinv_batch_deferred(d - 1, om, lt[1], rr(0), pv, stream));
+        bool same = true;
+        for (int mu = 1; mu < d - 1; ++mu) same = same && s[mu + 1] == s[1];
+        const double *A[SK_MAXB], *B[SK_MAXB];
+        double *C[SK_MAXB];
+        for (int mu = 0; mu < d - 1; ++mu) { A[mu] = ch.Rc[d - 2 - mu]; B[mu] = pv[mu]; C[mu] = W0 + (size_t)mu * szW; W[mu] = C[mu]; }
+        int done = 0;
+        if (same) {
+            ttsk_gemm_desc g{};
+            g.batch = 1; g.M = s[1]; g.N = lt[1]; g.Ko = 1; g.Ki = rr(0);
+            g.a_m = rr(0); g.a_ki = 1; g.b_ki = lt[1]; g.b_n = 1; g.c_m = lt[1]; g.c_n = 1; g.alpha = 1.0;
+            CK(done = small_try_batch(g, d - 1, A, B, C, stream, st));
+        }
+        if (!done)
+            for (int mu = 0; mu < d - 1; ++mu) CK(gemm2(s[mu + 1], lt[1], rr(0), A[mu], rr(0), 1, B[mu], lt[1], 1, C[mu], stream));
+    } else {
+        for (int mu = 0; mu < d - 1; ++mu) W[mu] = ch.Rc[d - 2 - mu];
+    }
+    // ---- 3. the modes
+    double *Lc = Lb, *Ln = Lb + szL;                      // Q-chain (s[mu] x k_{mu-1}) of this mode / of the next one
+    for (int mu = 0; mu < d; ++mu) {
+        const int64_t kp = kk(mu - 1), nn = n[mu], sn = s[mu], sp = s[mu + 1], m = kp * nn;
+        const double *Tm;
+        if (mu == 0) {
+            Tm = X[0];                                    // (n_0 x s_1)
+        } else {
+            // T[q, i, p'] = sum_p Lc[p, q] X[p, i, p']
+            double *dst = mu == d - 1 ? cores_out[mu] : T;
+            CK(gemm2(kp, nn * sp, sn, Lc, 1, kp, X[mu], nn * sp, 1, dst, stream));
+            Tm = dst;
+        }
+        if (mu == d - 1) {
+            if (mu == 0) TTSK_HIP(hipMemcpyAsync(cores_out[0], X[0], (size_t)nn * 8, hipMemcpyDeviceToDevice, st));
+            break;
+        }
+        const int64_t k = kk(mu);
+        double *Q = cores_out[mu];
+        CK(gemm2(m, k, sp, Tm, sp, 1, W[mu], k, 1, Q, stream));                     // M = T W
+        rc = qr_cholesky(Q, m, k, stream, st, qws, sticky);
+        if (rc < 0) return rc;
+        if (rc == 0) { set_error("ttsk_tt_orth_sketch: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+        // next chain matrix Ln[p', q'] = sum_{(q,i)} T[(q,i), p'] Q[(q,i), q']
+        CK(gemm2(sp, k, m, Tm, 1, sp, Q, k, 1, Ln, stream));
+        std::swap(Lc, Ln);
+    }
+#undef CK
+    return TTSK_OK;
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@ the host once, when the ``SketchContainer`` is built.
 from __future__ import annotations
 
 import ctypes
+import os
 import enum
 from functools import partial
 from typing import Callable, List, Optional, Tuple
@@ -193,16 +194,22 @@ def general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DR
         dense_sketch.clear_shared()
 
 
+_ONE_CALL_ORTH = os.environ.get("TTSK_ORTH_ONE_CALL", "1") != "0"
+
+
 def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
                            method: SketchMethod) -> Tuple[List[DevArray], List[DevArray]]:
     if method in (SketchMethod.hmt, SketchMethod.orthogonal):
         # Optimistic pass: every orthogonalisation as one call on the fast factorisations, no verdict awaited (the
         # d - 1 steps are sequential in mu: each blocking read-back drains the queue).  ONE read-back at the end; a
         # rejected factorisation (rank-deficient Omega, ill-conditioned unfolding) repeats the sketch on the robust path.
-        try:
-            out = _sketch_pass(tensor, left_drm, right_drm, method, deferred=True)
-        except nat.TtskUnsupported:
-            out = None
+        from . import tt_fused
+        out = tt_fused.try_orth_sketch(tensor, left_drm, right_drm, method) if _ONE_CALL_ORTH else None
+        if out is None:
+            try:
+                out = _sketch_pass(tensor, left_drm, right_drm, method, deferred=True)
+            except nat.TtskUnsupported:
+                out = None
         flag = ctypes.c_int(0)
         nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
         if out is not None and not flag.value:

@@ -143,3 +143,48 @@ def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[lis
         plan.run_sum((ctypes.c_void_p * len(flat))(*flat), len(tts), out, accumulate=not first)
         first = False
     return plan0.views(out)
+
+
+def try_orth_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list, list]]:
+    """``orthogonal`` / ``hmt`` sketch of ONE tensor train with tensor-train DRMs through ``ttsk_tt_orth_sketch``:
+    (cores, Omega) as device arrays, or None if the one-call path does not apply.  The verdicts of its fast
+    factorisations are deferred -- the caller reads ``ttsk_deferred_status`` (reference sketch_dispatch.py:160-193)."""
+    from .sketch_dispatch import SketchMethod
+    if method not in (SketchMethod.orthogonal, SketchMethod.hmt) or type(tensor) is not TensorTrain:
+        return None
+    orth = method == SketchMethod.orthogonal
+    if type(right_drm) is not TensorTrainDRM or not right_drm.transpose:
+        return None
+    if orth and (type(left_drm) is not TensorTrainDRM or left_drm.transpose):
+        return None
+    d = len(tensor.shape)
+    drms = [right_drm] + ([left_drm] if orth else [])
+    if d < 2 or any(len(m.cores) != d - 1 or tuple(m.shape) != tuple(tensor.shape) for m in drms):
+        return None
+    if any(tuple(m.rank_min) != (0,) * (d - 1) or tuple(m.rank_max) != tuple(m.true_rank) for m in drms):
+        return None                                   # a rank slice of a blocked sketch: the general path
+    arr = lambda v: (_I64 * len(v))(*[int(x) for x in v])
+    P = ctypes.c_void_p
+    n, s = arr(tensor.shape), arr((1,) + tuple(tensor.rank) + (1,))
+    rt = arr((1,) + tuple(right_drm.true_rank))
+    keep = [[c.contiguous() for c in tensor.dev_cores()], [c.contiguous() for c in right_drm.dev_cores()]]
+    X = (P * d)(*[c.ptr for c in keep[0]])
+    DR = (P * (d - 1))(*[c.ptr for c in keep[1]])
+    right_rank = tuple(right_drm.rank[::-1])
+    if orth:
+        lt = arr((1,) + tuple(left_drm.true_rank))
+        keep.append([c.contiguous() for c in left_drm.dev_cores()])
+        DL = (P * (d - 1))(*[c.ptr for c in keep[2]])
+        out_rank = tuple(left_drm.rank)
+        Omega = [DevArray.empty((out_rank[mu], right_rank[mu])) for mu in range(d - 1)]
+        om = (P * (d - 1))(*[o.ptr for o in Omega])
+    else:
+        lt, DL, om, Omega = None, None, None, []
+        out_rank = right_rank
+    kr = (1,) + out_rank + (1,)
+    cores = [DevArray.empty((kr[mu], tensor.shape[mu], kr[mu + 1])) for mu in range(d)]
+    try:
+        nat.call("ttsk_tt_orth_sketch", d, n, s, lt, rt, X, DL, DR, (P * d)(*[c.ptr for c in cores]), om, 0)
+    except nat.TtskUnsupported:
+        return None
+    return cores, Omega
