@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     __shared__ double shadow[2 * 128];
     int j = 0;
     bool expanded = false;
-    if (Qtop && expand) {
+    if ((Qtop && expand) || expand == 2) {                  // expand == 2: a second factorisation whose signs come later
         // The second factorisation of CholeskyQR2 sees G = I + E with |E| ~ n kappa(A)^2 eps.  For n max|E| <= 1e-8 the
         // factor's inverse is I - Phi(E) (Phi: strict upper triangle + half the diagonal) to within n |E|^2 < 1e-17:
         // no recurrence at all (n / 2 steps of ~1600 cycles otherwise).
@@ -1016,7 +1016,7 @@ size_t qr_ws_elems(int64_t m, int n) { return (size_t)m * n + 4 * (size_t)n * n 
 
 // thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected.  sticky: deferred mode -- the
 // factorisation always runs to the end (A is overwritten either way), a rejection is recorded in *sticky.
-int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in, int *sticky)
+int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in, int *sticky, bool unsigned_q)
 {
     const int n = (int)n64;
     if (n > CHOL_MAX || m < n) return 0;
@@ -1029,7 +1029,7 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
         }
         hipLaunchKernelGGL(small_qr_kernel, dim3(1), dim3(1024), ((size_t)m * n + n) * 8, st, A, (int)m, n);
         TTSK_LAUNCH_CHECK();
-        return 1;
+        return unsigned_q ? 2 : 1;        // 2: Q carries LAPACK's signs already
     }
     double *ws = ws_in ? ws_in : (double *)scratch(stream, SCRATCH_MISC, qr_ws_elems(m, n) * 8);
     if (!ws) return TTSK_ERR_HIP;
@@ -1041,7 +1041,13 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
     if ((rc = chol_inv_any(G, n, R1, nullptr, status, 1e-6, stream, st, cws, sticky))) return rc;       // kappa(A) up to ~1e6
     if ((rc = small_gemm(m, n, n, A, n, 1, R1, n, 1, Q1, stream))) return rc;            // Q1 = A R1^-1
     if ((rc = small_gemm(n, n, m, Q1, 1, n, Q1, n, 1, G, stream))) return rc;            // Q1^T Q1
-    if (n <= CHOL_SIGN_MAX) {
+    if (unsigned_q && n <= CHOL_ONE) {
+        // R with positive diagonal only: the caller reconstructs the signs beside the critical path (qr_signs)
+        static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, R2, (double *)nullptr,
+                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)nullptr, 0, chol_expand ? 2 : 0);
+        TTSK_LAUNCH_CHECK();
+    } else if (n <= CHOL_SIGN_MAX) {
         // second factorisation (G ~ identity), top block of Q and the sign reconstruction in ONE kernel
         static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
         static bool attr = false;
@@ -1071,6 +1077,97 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
         if (host_status[0] || host_status[1]) return 0;
     }
     if ((rc = small_gemm(m, n, n, Q1, n, 1, R2, n, 1, A, stream))) return rc;            // Q = Q1 R2^-1 S
+    return 1;
+}
+
+// The Householder column signs of Q = D Qc (Qc: top n x n block of a CholeskyQR factor with positive diagonal R, D a
+// +-1 scaling of its rows given per group of `rows_per` rows -- the signs of the previous mode's factor, which scale the
+// rows of this mode's unfolding): S[c] for the caller to apply whenever it likes.  One workgroup.
+__global__ __launch_bounds__(256) void qr_signs_kernel(const double *__restrict__ Qtop, int n, int square,
+                                                       const double *__restrict__ Sprev, int rows_per, double *__restrict__ Sout)
+{
+    extern __shared__ double sm[];
+    const int ld = n + 1, tid = threadIdx.x;
+    double *B = sm, *S = sm + n * ld;
+    __shared__ double shadow[2 * 128];
+    for (int e = tid; e < n * n; e += 256) {
+        const int r = e / n;
+        B[r * ld + e % n] = Qtop[e] * (Sprev ? Sprev[r / rows_per] : 1.0);
+    }
+    __syncthreads();
+    hh_signs_lds(B, n, ld, square, S, shadow, tid);
+    for (int c = tid; c < n; c += 256) Sout[c] = S[c];
+}
+
+int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st)
+{
+    if (n > CHOL_ONE) return 0;
+    static bool attr = false;
+    if (!attr) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)qr_signs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(qr_signs_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n, square, Sprev, rows_per, Sout);
+    TTSK_LAUNCH_CHECK();
+    return 1;
+}
+
+// core[a, i, b] *= sp[a] sn[b] for up to 16 cores in one launch (sp / sn may be nullptr = all ones)
+struct SignFix { double *core[16]; const double *sp[16], *sn[16]; int k0[16], nn[16], k1[16]; };
+__global__ void apply_signs_kernel(SignFix f)
+{
+    const int q = blockIdx.y;
+    double *c = f.core[q];
+    const double *sp = f.sp[q], *sn = f.sn[q];
+    const int64_t k1 = f.k1[q], per = (int64_t)f.nn[q] * k1, tot = (int64_t)f.k0[q] * per;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const double s = (sp ? sp[e / per] : 1.0) * (sn ? sn[e % k1] : 1.0);
+        c[e] *= s;
+    }
+}
+int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
+                const int *k1, hipStream_t st)
+{
+    for (int c0 = 0; c0 < count; c0 += 16) {
+        SignFix f{};
+        const int cnt = count - c0 < 16 ? count - c0 : 16;
+        for (int q = 0; q < cnt; ++q) {
+            f.core[q] = cores[c0 + q]; f.sp[q] = sp[c0 + q]; f.sn[q] = sn[c0 + q];
+            f.k0[q] = k0[c0 + q]; f.nn[q] = nn[c0 + q]; f.k1[q] = k1[c0 + q];
+        }
+        hipLaunchKernelGGL(apply_signs_kernel, dim3(64, cnt), dim3(256), 0, st, f);
+        TTSK_LAUNCH_CHECK();
+    }
+    return TTSK_OK;
+}
+
+size_t qr_mul_ws_elems(int64_t m, int n) { return (size_t)m * n + 3 * (size_t)n * n + 16 + tall_mul_ws_elems(m, n); }
+
+int qr_cholesky_mul(const double *A, int64_t lda, int K, const double *W, double *Q, int64_t m, int n, int stream, hipStream_t st,
+                    double *ws, int *sticky, bool unsigned_q)
+{
+    if (!sticky || !ws || n > 64 || n > CHOL_SIGN_MAX || m < 2 * (int64_t)n) return 0;
+    double *Q1 = ws, *G = Q1 + (size_t)m * n, *R1 = G + n * n, *R2 = R1 + n * n;
+    int *status = (int *)(R2 + n * n);
+    double *slab = R2 + n * n + 16;
+    int rc = tall_mul(A, lda, K, W, n, Q, n, m, n, G, slab, st);                          // M = A W, G = M^T M
+    if (rc <= 0) return rc;
+    if ((rc = launch_chol(G, n, R1, nullptr, status, 1e-6, st, sticky))) return rc;      // kappa(M) up to ~1e6
+    if ((rc = tall_mul(Q, n, n, R1, n, Q1, n, m, n, G, slab, st)) <= 0) return rc ? rc : TTSK_ERR_UNSUPPORTED;   // Q1 = M R1^-1, G = Q1^T Q1
+    static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
+    static bool attr = false;
+    if (!attr) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        attr = true;
+    }
+    if (unsigned_q)
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, R2, (double *)nullptr,
+                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)nullptr, 0, chol_expand ? 2 : 0);
+    else
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(3 * n * (n + 1) + 2 * n) * 8, st, G, n, R2, (double *)nullptr,
+                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, 0, chol_expand);
+    TTSK_LAUNCH_CHECK();
+    if ((rc = tall_mul(Q1, n, n, R2, n, Q, n, m, n, nullptr, nullptr, st)) <= 0) return rc ? rc : TTSK_ERR_UNSUPPORTED;   // Q = Q1 R2^-1 S
     return 1;
 }
 

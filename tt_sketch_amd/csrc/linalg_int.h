@@ -11,7 +11,25 @@ int *deferred_flag(int stream);          // the stream's sticky rejection word (
 size_t qr_ws_elems(int64_t m, int n);    // doubles of workspace qr_cholesky needs
 // thin QR in place by CholeskyQR2 with LAPACK's column signs; 1 = queued, 0 = outside the fast path, < 0 = error.
 // sticky: deferred verdict (no read-back; a rejection sets *sticky)
-int qr_cholesky(double *A, int64_t m, int64_t n, int stream, hipStream_t st, double *ws_in = nullptr, int *sticky = nullptr);
+int qr_cholesky(double *A, int64_t m, int64_t n, int stream, hipStream_t st, double *ws_in = nullptr, int *sticky = nullptr,
+                bool unsigned_q = false);
+// unsigned_q (n <= 128): Q comes out with the signs of CholeskyQR (R's diagonal positive) and the sign reconstruction is
+// left to the caller (qr_signs on the top n x n block of Q, beside the critical path; apply_signs at the end);
+// return value 2 = the one-workgroup Householder kernel ran instead: Q carries LAPACK's signs already.
+int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st);
+int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
+                const int *k1, hipStream_t st);
 constexpr int QR_CHOL_MAX_N = 256;       // largest column count of qr_cholesky
+// Q (m x n) = Householder-signed Q of qr_thin(A W), A (m x K, row stride lda), W (K x n): the product and both Gram
+// matrices of CholeskyQR2 from the fused tall kernels (tall_qr.hip).  Deferred verdicts only (sticky != nullptr).
+// 1 = queued, 0 = outside these kernels (n > 64, K W beyond the LDS, nearly square) -- nothing was queued
+size_t qr_mul_ws_elems(int64_t m, int n);
+int qr_cholesky_mul(const double *A, int64_t lda, int K, const double *W, double *Q, int64_t m, int n, int stream, hipStream_t st,
+                    double *ws, int *sticky, bool unsigned_q = false);
+// tall_qr.hip: Y = A B and, G != nullptr, G = Y^T Y (slab: tall_mul_ws_elems doubles); 1 = queued, 0 = not covered
+size_t tall_mul_ws_elems(int64_t m, int n);
+int tall_mul(const double *A, int64_t lda, int K, const double *B, int64_t ldb, double *Y, int64_t ldy, int64_t m, int n,
+             double *G, double *slab, hipStream_t st);
+
 
 }  // namespace ttsk

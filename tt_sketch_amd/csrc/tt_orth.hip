@@ -11,6 +11,7 @@
 // Nothing is read back: the verdicts of the fast factorisations accumulate in the stream's deferred flag
 // (ttsk_deferred_status); the caller repeats a rejected sketch on the robust path (ttsk_pinv / ttsk_qr_thin).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "common.h"
 #include "skinny.h"
@@ -77,10 +78,13 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     // ---- workspace of this driver
     auto blk = [](size_t v) { return (v + 31) & ~(size_t)31; };
     const size_t szP = orth ? blk((size_t)rr(0) * lt[1]) : 0, szW = orth ? blk((size_t)smax * lt[1]) : 0;
-    const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax), szQ = blk(qr_ws_elems(mmax, (int)kmax));
-    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW) + 2 * szL + szT + szQ) * 8);
+    const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax);
+    const size_t szQ = blk(std::max(qr_ws_elems(mmax, (int)kmax), qr_mul_ws_elems(mmax, (int)kmax)));
+    static const int tall_on = [] { const char *e = getenv("TTSK_ORTH_TALL"); return e ? atoi(e) : 0; }();   // (tall_qr.hip: not faster yet)
+    const size_t szS = blk((size_t)kmax);
+    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW + szS) + 2 * szL + szT + szQ) * 8);
     if (!ws) return TTSK_ERR_HIP;
-    double *P0 = ws, *W0 = P0 + (size_t)(d - 1) * szP, *Lb = W0 + (size_t)(d - 1) * szW, *T = Lb + 2 * szL, *qws = T + szT;
+    double *P0 = ws, *W0 = P0 + (size_t)(d - 1) * szP, *Lb = W0 + (size_t)(d - 1) * szW, *T = Lb + 2 * szL, *qws = T + szT, *Sb = qws + szQ;
     // ---- 2. W_mu = R_mu Omega_mu^+  (s[mu+1] x l)
     std::vector<const double *> W(d - 1);
     if (orth) {
@@ -105,8 +109,18 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     } else {
         for (int mu = 0; mu < d - 1; ++mu) W[mu] = ch.Rc[d - 2 - mu];
     }
-    // ---- 3. the modes
+    // ---- 3. the modes.  The Householder column signs are NOT on this chain: the factors come out with CholeskyQR's
+    // signs (Q~), the chain goes on with Q~ -- a sign flip of column b of Q_mu flips row b of the next chain matrix and
+    // with it the rows (b, i) of the next unfolding, which changes neither that unfolding's R nor Q~ beyond the same row
+    // flips -- and the sign reconstruction of every mode (an n-step elimination in one workgroup) runs on the helper
+    // stream beside the next mode's products.  One pass over the cores at the end applies S_{mu-1} (rows) and S_mu (columns).
+    static const int signs_beside = [] { const char *e = getenv("TTSK_ORTH_SIGNS_BESIDE"); return e ? atoi(e) : 1; }();
+    bool beside = signs_beside && kmax <= 128;
+    for (int mu = 1; mu < d - 1; ++mu) beside = beside && kk(mu - 1) * n[mu] >= 2 * kk(mu);   // (the one-workgroup Householder QR of a nearly square unfolding signs its Q itself: only mode 0 may take it)
+    const int aux = (stream + 1) % TTSK_NUM_STREAMS;
+    TTSK_STREAM(st_aux, aux);
     double *Lc = Lb, *Ln = Lb + szL;                      // Q-chain (s[mu] x k_{mu-1}) of this mode / of the next one
+    std::vector<const double *> Sg(d, nullptr);           // signs of mode mu (nullptr: none / all ones)
     for (int mu = 0; mu < d; ++mu) {
         const int64_t kp = kk(mu - 1), nn = n[mu], sn = s[mu], sp = s[mu + 1], m = kp * nn;
         const double *Tm;
@@ -124,13 +138,35 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
         }
         const int64_t k = kk(mu);
         double *Q = cores_out[mu];
-        CK(gemm2(m, k, sp, Tm, sp, 1, W[mu], k, 1, Q, stream));                     // M = T W
-        rc = qr_cholesky(Q, m, k, stream, st, qws, sticky);
+        rc = tall_on ? qr_cholesky_mul(Tm, sp, (int)sp, W[mu], Q, m, (int)k, stream, st, qws, sticky, beside) : 0;   // Q = qr(T W)
         if (rc < 0) return rc;
-        if (rc == 0) { set_error("ttsk_tt_orth_sketch: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+        if (rc == 0) {
+            CK(gemm2(m, k, sp, Tm, sp, 1, W[mu], k, 1, Q, stream));                 // M = T W
+            rc = qr_cholesky(Q, m, k, stream, st, qws, sticky, beside);
+            if (rc < 0) return rc;
+            if (rc == 0) { set_error("ttsk_tt_orth_sketch: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+        }
+        if (beside && rc == 2 && mu > 0) { set_error("ttsk_tt_orth_sketch: unexpected small unfolding"); return TTSK_ERR_UNSUPPORTED; }
+        if (beside && rc != 2) {
+            double *Sm = Sb + (size_t)mu * szS;
+            CK(ttsk_stream_wait(aux, stream));                                     // Q~ is there
+            CK(qr_signs(Q, (int)k, m == k ? 1 : 0, mu > 0 ? Sg[mu - 1] : nullptr, (int)nn, Sm, st_aux));
+            Sg[mu] = Sm;
+        }
         // next chain matrix Ln[p', q'] = sum_{(q,i)} T[(q,i), p'] Q[(q,i), q']
         CK(gemm2(sp, k, m, Tm, 1, sp, Q, k, 1, Ln, stream));
         std::swap(Lc, Ln);
+    }
+    if (beside) {
+        CK(ttsk_stream_wait(stream, aux));
+        std::vector<double *> cs(d);
+        std::vector<const double *> spv(d), snv(d);
+        std::vector<int> k0(d), nv(d), k1(d);
+        for (int mu = 0; mu < d; ++mu) {
+            cs[mu] = cores_out[mu]; spv[mu] = mu > 0 ? Sg[mu - 1] : nullptr; snv[mu] = mu < d - 1 ? Sg[mu] : nullptr;
+            k0[mu] = (int)kk(mu - 1); nv[mu] = (int)n[mu]; k1[mu] = mu < d - 1 ? (int)kk(mu) : 1;
+        }
+        CK(apply_signs(d, cs.data(), spv.data(), snv.data(), k0.data(), nv.data(), k1.data(), st));
     }
 #undef CK
     return TTSK_OK;
