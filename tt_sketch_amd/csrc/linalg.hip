@@ -1114,15 +1114,18 @@ int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int row
 
 // core[a, i, b] *= sp[a] sn[b] for up to 16 cores in one launch (sp / sn may be nullptr = all ones)
 struct SignFix { double *core[16]; const double *sp[16], *sn[16]; int k0[16], nn[16], k1[16]; };
-__global__ void apply_signs_kernel(SignFix f)
+__global__ __launch_bounds__(256) void apply_signs_kernel(SignFix f)
 {
     const int q = blockIdx.y;
     double *c = f.core[q];
     const double *sp = f.sp[q], *sn = f.sn[q];
-    const int64_t k1 = f.k1[q], per = (int64_t)f.nn[q] * k1, tot = (int64_t)f.k0[q] * per;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
-        const double s = (sp ? sp[e / per] : 1.0) * (sn ? sn[e % k1] : 1.0);
-        c[e] *= s;
+    const int k1 = f.k1[q], rows = f.k0[q] * f.nn[q], nn = f.nn[q];
+    // a row (a, i) per 16-lane group and step, its k1 entries 16 at a time
+    const int grp = threadIdx.x >> 4, x = threadIdx.x & 15;
+    for (int r = blockIdx.x * 16 + grp; r < rows; r += gridDim.x * 16) {
+        const double sr = sp ? sp[r / nn] : 1.0;
+        double *row = c + (size_t)r * k1;
+        for (int b = x; b < k1; b += 16) row[b] *= sn ? sr * sn[b] : sr;
     }
 }
 int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
@@ -1135,7 +1138,7 @@ int apply_signs(int count, double *const *cores, const double *const *sp, const 
             f.core[q] = cores[c0 + q]; f.sp[q] = sp[c0 + q]; f.sn[q] = sn[c0 + q];
             f.k0[q] = k0[c0 + q]; f.nn[q] = nn[c0 + q]; f.k1[q] = k1[c0 + q];
         }
-        hipLaunchKernelGGL(apply_signs_kernel, dim3(64, cnt), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(apply_signs_kernel, dim3(160, cnt), dim3(256), 0, st, f);
         TTSK_LAUNCH_CHECK();
     }
     return TTSK_OK;
@@ -1409,9 +1412,18 @@ int ttsk_deferred_status(int stream, int *host_flag)
     TTSK_ARG(host_flag, "ttsk_deferred_status: NULL argument");
     int *sticky = deferred_flag(stream);
     TTSK_ARG(sticky, "ttsk_deferred_status: no device flag");
-    TTSK_HIP(hipMemcpyAsync(host_flag, sticky, sizeof(int), hipMemcpyDeviceToHost, st));
+    // through a pinned word: a copy into the caller's pageable int is staged and blocks for ~40 us before the reset is
+    // even queued
+    static int *pinned = [] {
+        int *q = nullptr;
+        if (hipHostMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int), hipHostMallocDefault) != hipSuccess) q = nullptr;
+        return q;
+    }();
+    int *dst = pinned ? pinned + stream : host_flag;
+    TTSK_HIP(hipMemcpyAsync(dst, sticky, sizeof(int), hipMemcpyDeviceToHost, st));
     TTSK_HIP(hipMemsetAsync(sticky, 0, sizeof(int), st));
     TTSK_HIP(hipStreamSynchronize(st));
+    if (pinned) *host_flag = *dst;
     return TTSK_OK;
 }
 

@@ -90,6 +90,46 @@ __global__ __launch_bounds__(256) void skinny_r_reduce2(const double2 *__restric
     }
 }
 
+// many chunks of one small result (the fused chain step of a single tensor: one partial per mode index): 64 element
+// pairs x 16 chunk groups per block -- a wave reads 1 KB of one chunk per instruction instead of four 256-byte pieces
+__global__ __launch_bounds__(1024) void skinny_r_reduce2w(const double2 *__restrict__ slab_all, int chunks, int M, int N,
+                                                          int m_tiles, int64_t Mtot, ReduceOut outs, int64_t c_m, double alpha,
+                                                          int accumulate)
+{
+    __shared__ double2 part[16][65];
+    const int prob = blockIdx.y / m_tiles, tile = blockIdx.y - prob * m_tiles;
+    const int64_t MN2 = (int64_t)M * N / 2;
+    const double2 *__restrict__ slab = slab_all + (int64_t)blockIdx.y * chunks * MN2;
+    double *__restrict__ C = outs.C[prob];
+    const int x = threadIdx.x & 63, z = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + x;
+    double2 sum = make_double2(0.0, 0.0);
+    if (e < MN2) {
+        double2 v[8];
+        for (int c0 = z; c0 < chunks; c0 += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c0 + 16 * u < chunks ? slab[(int64_t)(c0 + 16 * u) * MN2 + e] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; }
+        }
+    }
+    part[z][x] = sum;
+    __syncthreads();
+    if (z == 0 && e < MN2) {
+        double2 tot = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { tot.x += part[k][x].x; tot.y += part[k][x].y; }
+        const int m = (int)(2 * e / N), n = (int)(2 * e - (int64_t)m * N);
+        const int64_t row = (int64_t)tile * M + m;
+        if (row < Mtot) {
+            double2 *c = reinterpret_cast<double2 *>(C + row * c_m + n);
+            double2 o = make_double2(alpha * tot.x, alpha * tot.y);
+            if (accumulate) { const double2 old = *c; o.x += old.x; o.y += old.y; }
+            *c = o;
+        }
+    }
+}
+
 int launch_r_reduce(hipStream_t st, const double *slab, int chunks, int M, int N, int m_tiles, int64_t Mtot, const ReduceOut &ro,
                     int nprob, int64_t c_m, int64_t c_n, double alpha, int accumulate)
 {
@@ -97,7 +137,11 @@ int launch_r_reduce(hipStream_t st, const double *slab, int chunks, int M, int N
     bool vec = c_n == 1 && !(N & 1) && !(c_m & 1) && !((uintptr_t)slab & 15);
     for (int b = 0; b < nprob && vec; ++b) vec = !((uintptr_t)ro.C[b] & 15);
     const unsigned gy = (unsigned)(nprob * m_tiles);
-    if (vec)
+    static const int wide = [] { const char *e = getenv("TTSK_REDUCE_WIDE"); return e ? atoi(e) : 1; }();
+    if (vec && wide && chunks >= 64 && gy * cdiv(mn / 2, 64) >= 64)
+        hipLaunchKernelGGL(skinny_r_reduce2w, dim3((unsigned)cdiv(mn / 2, 64), gy), dim3(1024), 0, st, (const double2 *)slab, chunks, M,
+                           N, m_tiles, Mtot, ro, c_m, alpha, accumulate);
+    else if (vec)
         hipLaunchKernelGGL(skinny_r_reduce2, dim3((unsigned)cdiv(mn / 2, 16), gy), dim3(256), 0, st, (const double2 *)slab, chunks, M, N,
                            m_tiles, Mtot, ro, c_m, alpha, accumulate);
     else

@@ -24,9 +24,8 @@ struct TallMul {
     int K, n, tiles;
 };
 
-constexpr int TM_KC = 32;       // k-blocks (of 4) whose A operands a wave holds at once: all of K <= 128 in one go
-
 __host__ __device__ constexpr int tm_sb(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }   // row stride of B in LDS: = 16 mod 32
+__host__ __device__ inline int tm_sa(int K4) { return 4 * K4 + 2; }                                // row stride of an A tile: half of it odd
 
 template <int NT, bool GRAM>
 __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched with 256 threads: the bound keeps the compiler off the AGPR file
@@ -34,35 +33,52 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
     extern __shared__ double sm[];
     constexpr int SB = tm_sb(NT), NP = NT * (NT + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, x16 = lane & 15, g = lane >> 4;
-    const int K4 = (p.K + 3) >> 2;
+    const int K4 = (p.K + 3) >> 2, SA = tm_sa(K4);
+    double *As = sm + (size_t)K4 * 4 * SB + (size_t)wv * 16 * SA;          // this wave's 16 x K tile of A
     int tile = blockIdx.x * 4 + wv;
-    // the A operands of the first tile are on their way while B is staged
-    double a[TM_KC];
-    // (unconditional loads from clamped addresses: rows of B beyond K are zero in LDS, rows beyond m are masked after
-    // the product -- a select behind every load makes the compiler wait for each one)
-    auto load_a = [&](int t, int kb0) {
-        const int64_t row = (int64_t)t * 16 + x16;
-        const double *ar = p.A + (row < p.m ? row : p.m - 1) * p.lda;
+    // A tile -> LDS, row by row (coalesced: 64 consecutive doubles per instruction); the columns K .. 4 K4 are zeroed
+    auto stage_a = [&](int t) {
+        double v[16][2];
+        if (p.K <= 128) {
 #pragma unroll
-        for (int i = 0; i < TM_KC; ++i) {
-            const int k = 4 * (kb0 + i) + g;
-            a[i] = ar[k < p.K ? k : p.K - 1];
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = (int64_t)t * 16 + r;
+                const double *ar = p.A + (row < p.m ? row : p.m - 1) * p.lda;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = lane + 64 * h;
+                    v[r][h] = ar[k < p.K ? k : p.K - 1];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = lane + 64 * h;
+                    if (k < 4 * K4) As[r * SA + k] = k < p.K ? v[r][h] : 0.0;
+                }
+        } else {
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = (int64_t)t * 16 + r;
+                const double *ar = p.A + (row < p.m ? row : p.m - 1) * p.lda;
+                for (int k = lane; k < 4 * K4; k += 64) As[r * SA + k] = k < p.K ? ar[k] : 0.0;
+            }
         }
     };
-    load_a(tile < p.tiles ? tile : 0, 0);
+    if (tile < p.tiles) stage_a(tile);
     {
-        // B (K x n) -> LDS rows of SB doubles, zero padded; eight loads in flight per thread
+        // B (K x n) -> LDS rows of SB doubles, zero padded; sixteen loads in flight per thread
         const int total = K4 * 4 * SB;
-        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
-            double v[8];
+        for (int e0 = tid; e0 < total; e0 += 256 * 16) {
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int e = e0 + 256 * u, k = e / SB, c = e - k * SB;
                 const bool ok = e < total && k < p.K && c < p.n;
                 v[u] = ok ? p.B[(int64_t)k * p.ldb + c] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (e0 + 256 * u < total) sm[e0 + 256 * u] = v[u];
         }
     }
@@ -74,17 +90,12 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
         v4d acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-        for (int kb0 = 0; kb0 < K4; kb0 += TM_KC) {
-            if (kb0) load_a(tile, kb0);
+        const double *ap = As + x16 * SA + g, *bp = sm + g * SB + x16;
+#pragma unroll 4
+        for (int kb = 0; kb < K4; ++kb) {
+            const double a = ap[4 * kb];
 #pragma unroll
-            for (int i = 0; i < TM_KC; ++i) {
-                if (kb0 + i < K4) {
-                    const double *br = sm + (4 * (kb0 + i) + g) * SB + x16;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = mfma16(a[i], br[16 * t], acc[t]);
-                }
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // keeps the LDS reads of later k-blocks out of the registers
-            }
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(a, bp[4 * kb * SB + 16 * t], acc[t]);
         }
         if ((int64_t)tile * 16 + 16 > p.m) {                                         // the last tile: rows beyond m are not there
 #pragma unroll
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
                 for (int j = 0; j < 4; ++j)
                     if ((int64_t)tile * 16 + g + 4 * j >= p.m) acc[t][j] = 0.0;
         }
-        if (tile + gridDim.x * 4 < p.tiles) load_a(tile + gridDim.x * 4, 0);       // the next tile's operands behind the stores
+        if (tile + gridDim.x * 4 < p.tiles) stage_a(tile + gridDim.x * 4);          // (this wave alone reads and writes its tile: program order suffices)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -103,17 +114,18 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
                 if (r < p.m && c < p.n) p.Y[r * p.ldy + c] = acc[t][j];
             }
         if (GRAM) {
-            int q = 0;
 #pragma unroll
-            for (int t1 = 0; t1 < NT; ++t1)
+            for (int j = 0; j < 4; ++j) {
+                int q = 0;
 #pragma unroll
-                for (int t2 = t1; t2 < NT; ++t2, ++q)
+                for (int t1 = 0; t1 < NT; ++t1)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gacc[q] = mfma16(acc[t1][j], acc[t2][j], gacc[q]);
+                    for (int t2 = t1; t2 < NT; ++t2, ++q) gacc[q] = mfma16(acc[t1][j], acc[t2][j], gacc[q]);
+            }
         }
     }
     if (GRAM) {
-        __syncthreads();                                   // every wave is done with B
+        __syncthreads();                                   // every wave is done with B and its A tile
         double *gs = sm + (size_t)wv * NP * 256;
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -126,27 +138,30 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
     }
 }
 
-// G (n x n, symmetric, full) = sum over the workgroups of their partial tiles; one block per tile pair, four groups
-// of 256 threads share the sum
+// G (n x n, symmetric, full) = sum over the workgroups of their partial tiles.  Block (x, pair): 32 consecutive
+// elements of the pair's tile, 32 thread groups each summing every 32nd partial (all its loads in flight at once),
+// then a fixed-order sum of the groups in LDS.
 __global__ __launch_bounds__(1024) void gram_reduce_kernel(const double *__restrict__ slab, int nwg, int nt, int n, double *__restrict__ G)
 {
-    __shared__ double part[4][256];
-    const int np = nt * (nt + 1) / 2, q = blockIdx.x, e = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    __shared__ double part[32][33];
+    const int np = nt * (nt + 1) / 2, q = blockIdx.y, x = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + x;
     double acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-    for (int w0 = grp; w0 < nwg; w0 += 32) {
+    for (int w0 = grp; w0 < nwg; w0 += 256) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int w = w0 + 4 * u;
+            const int w = w0 + 32 * u;
             if (w < nwg) acc[u] += slab[((size_t)w * np + q) * 256 + e];
         }
     }
-    const double s0 = (acc[0] + acc[1]) + (acc[2] + acc[3]), s1 = (acc[4] + acc[5]) + (acc[6] + acc[7]);
-    part[grp][e] = s0 + s1;
+    part[grp][x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (grp) return;
-    const double v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += part[k][x];
     int t1 = 0, rest = q;
     while (rest >= nt - t1) { rest -= nt - t1; ++t1; }
     const int t2 = t1 + rest, lane = e & 63, j = e >> 6;
@@ -188,7 +203,7 @@ int tall_mul(const double *A, int64_t lda, int K, const double *B, int64_t ldb, 
     const int nt = (n + 15) >> 4;
     if (nt < 1 || nt > 4 || K < 1 || m < 1) return 0;
     const int K4 = (K + 3) >> 2, np = nt * (nt + 1) / 2;
-    const size_t lds = std::max((size_t)K4 * 4 * tm_sb(nt), G ? (size_t)4 * np * 256 : (size_t)0) * 8;
+    const size_t lds = std::max((size_t)K4 * 4 * tm_sb(nt) + (size_t)4 * 16 * tm_sa(K4), G ? (size_t)4 * np * 256 : (size_t)0) * 8;
     if (lds > 150 * 1024) return 0;
     const int64_t tiles = (m + 15) >> 4;
     if (tiles > (1 << 30)) return 0;
@@ -203,10 +218,29 @@ int tall_mul(const double *A, int64_t lda, int K, const double *B, int64_t ldb, 
     }
     if (rc < 0) return rc;
     if (G) {
-        hipLaunchKernelGGL(gram_reduce_kernel, dim3(np), dim3(1024), 0, st, slab, nwg, nt, n, G);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(8, np), dim3(1024), 0, st, slab, nwg, nt, n, G);
         TTSK_LAUNCH_CHECK();
     }
     return 1;
 }
 
 }  // namespace ttsk
+
+// Y (m x n) = A (m x K) B (K x n), contiguous row-major, and (G != NULL) G (n x n) = Y^T Y: the fused kernel behind
+// ttsk_tt_orth_sketch's CholeskyQR2 steps, exported for the parity tests and the profiling scripts.
+extern "C" int ttsk_tall_mul(const double *A, int64_t m, int64_t K, const double *B, int64_t n, double *Y, double *G, int stream)
+{
+    using namespace ttsk;
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(A && B && Y && m >= 1 && K >= 1 && n >= 1, "ttsk_tall_mul: bad argument");
+    double *slab = nullptr;
+    if (G) {
+        slab = (double *)scratch(stream, SCRATCH_MISC, tall_mul_ws_elems(m, (int)n) * 8);
+        if (!slab) return TTSK_ERR_HIP;
+    }
+    const int rc = (n <= 64 && K <= (1 << 20)) ? tall_mul(A, K, (int)K, B, n, Y, n, m, (int)n, G, slab, st) : 0;
+    if (rc < 0) return rc;
+    if (rc == 0) { set_error("ttsk_tall_mul: (%lld x %lld) (%lld x %lld) is outside the kernel", (long long)m, (long long)K, (long long)K, (long long)n); return TTSK_ERR_UNSUPPORTED; }
+    return TTSK_OK;
+}
+
