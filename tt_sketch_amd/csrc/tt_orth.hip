@@ -121,6 +121,17 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     TTSK_STREAM(st_aux, aux);
     double *Lc = Lb, *Ln = Lb + szL;                      // Q-chain (s[mu] x k_{mu-1}) of this mode / of the next one
     std::vector<const double *> Sg(d, nullptr);           // signs of mode mu (nullptr: none / all ones)
+    // core[a, i, b] *= S_{mu-1}[a] S_mu[b] on the helper stream, behind the sign kernels and behind the main stream's work so far
+    static const int fix_beside = [] { const char *e = getenv("TTSK_ORTH_FIX_BESIDE"); return e ? atoi(e) : 1; }();
+    auto fix_core = [&](int mu) -> int {
+        const double *spv = mu > 0 ? Sg[mu - 1] : nullptr, *snv = mu < d - 1 ? Sg[mu] : nullptr;
+        if (!spv && !snv) return TTSK_OK;
+        double *c = cores_out[mu];
+        const int k0 = (int)kk(mu - 1), nv = (int)n[mu], k1 = mu < d - 1 ? (int)kk(mu) : 1;
+        int r = ttsk_stream_wait(aux, stream);
+        if (r < 0) return r;
+        return apply_signs(1, &c, &spv, &snv, &k0, &nv, &k1, st_aux);
+    };
     for (int mu = 0; mu < d; ++mu) {
         const int64_t kp = kk(mu - 1), nn = n[mu], sn = s[mu], sp = s[mu + 1], m = kp * nn;
         const double *Tm;
@@ -156,17 +167,13 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
         // next chain matrix Ln[p', q'] = sum_{(q,i)} T[(q,i), p'] Q[(q,i), q']
         CK(gemm2(sp, k, m, Tm, 1, sp, Q, k, 1, Ln, stream));
         std::swap(Lc, Ln);
+        if (beside && fix_beside) CK(fix_core(mu));       // the chain has read Q~ for the last time
     }
     if (beside) {
+        if (!fix_beside)
+            for (int mu = 0; mu < d - 1; ++mu) CK(fix_core(mu));
+        CK(fix_core(d - 1));
         CK(ttsk_stream_wait(stream, aux));
-        std::vector<double *> cs(d);
-        std::vector<const double *> spv(d), snv(d);
-        std::vector<int> k0(d), nv(d), k1(d);
-        for (int mu = 0; mu < d; ++mu) {
-            cs[mu] = cores_out[mu]; spv[mu] = mu > 0 ? Sg[mu - 1] : nullptr; snv[mu] = mu < d - 1 ? Sg[mu] : nullptr;
-            k0[mu] = (int)kk(mu - 1); nv[mu] = (int)n[mu]; k1[mu] = mu < d - 1 ? (int)kk(mu) : 1;
-        }
-        CK(apply_signs(d, cs.data(), spv.data(), snv.data(), k0.data(), nv.data(), k1.data(), st));
     }
 #undef CK
     return TTSK_OK;
