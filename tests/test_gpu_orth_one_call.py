@@ -1,0 +1,181 @@
+"""ttsk_tt_orth_sketch: orthogonal_sketch / hmt_sketch of a TT with TT DRMs as one library call.
+
+What the one-call path does differently from the mode-by-mode path (sketch_dispatch.py:160-193 as the reference
+writes it): it never forms Psi_mu (Q_mu = qr(T R_mu Omega_mu^+)), it carries the chain on with the UNSIGNED
+CholeskyQR factor and reconstructs LAPACK's Householder column signs beside the critical path, and it applies
+the signs to the cores at the end.  So the cores are compared entry by entry (signs included) against the
+oracle's numpy QR, against the mode-by-mode device path, and the fallbacks are exercised.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import ttsk_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CORE_TOL = 1e-9            # entrywise, relative to the largest entry of the core (cores went through pinv and QR)
+
+
+@pytest.fixture(scope="module")
+def tsa():
+    import tt_sketch_amd
+    from tt_sketch_amd import _native
+    _native.call("ttsk_init", 0)
+    return tt_sketch_amd
+
+
+def _case(shape, s_in, l, r, seed):
+    rng = np.random.default_rng(seed)
+    cores = orc.random_tt(shape, s_in, rng)
+    ld = orc.random_tt_drm(shape, l, False, rng) if l is not None else None
+    rd = orc.random_tt_drm(shape, r, True, rng)
+    return cores, ld, rd
+
+
+def _dev_drms(tsa, shape, l, r, ld, rd):
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=[np.array(c) for c in rd.cores])
+    left = None if ld is None else tsa.TensorTrainDRM(l, shape, False, seed=1, cores=[np.array(c) for c in ld.cores])
+    return left, right
+
+
+def _one_call_ran(tsa, monkeypatch):
+    """count the calls that went through the one-call entry point"""
+    from tt_sketch_amd import tt_fused
+    hits = []
+    real = tt_fused.try_orth_sketch
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        hits.append(out is not None)
+        return out
+    monkeypatch.setattr(tt_fused, "try_orth_sketch", spy)
+    return hits
+
+
+def _close(got, want):
+    assert [np.asarray(c).shape for c in got] == [np.asarray(c).shape for c in want]
+    for k, (g, w) in enumerate(zip(got, want)):
+        g, w = np.asarray(g), np.asarray(w)
+        assert np.abs(g - w).max() <= CORE_TOL * np.abs(w).max(), f"core {k}"
+
+
+@pytest.mark.parametrize("shape,s_in,l,r", [
+    ((30, 28, 26, 24, 22), 12, 8, 16),           # d = 5, every mode size different
+    ((40, 40, 40, 40), 20, 16, 17),              # r = l + 1 (nearly square Omega)
+    ((64, 50, 50, 64), 33, 17, 40),              # odd ranks, r > 2 l
+    ((200, 200, 200), 60, 50, 64),               # four column tiles wide
+    ((12, 100, 100, 12), 10, 6, 9),              # first unfolding only twice as tall as wide
+])
+def test_orthogonal_one_call_cores_match_oracle_and_mode_by_mode(tsa, monkeypatch, shape, s_in, l, r):
+    from tt_sketch_amd import sketch_dispatch
+    d = len(shape)
+    cores, ld, rd = _case(shape, s_in, l, r, seed=sum(shape) + l)
+    left, right = _dev_drms(tsa, shape, (l,) * (d - 1), (r,) * (d - 1), ld, rd)
+    hits = _one_call_ran(tsa, monkeypatch)
+    X = tsa.TensorTrain(cores)
+    one = [np.asarray(c) for c in tsa.orthogonal_sketch(X, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right).cores]
+    assert hits == [True]
+    monkeypatch.setattr(sketch_dispatch, "_ONE_CALL_ORTH", False)
+    per_mode = [np.asarray(c) for c in tsa.orthogonal_sketch(X, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right).cores]
+    want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+    _close(one, want)
+    _close(one, per_mode)
+    for c in one[:-1]:
+        q = c.reshape(-1, c.shape[2])
+        assert np.linalg.norm(q.T @ q - np.eye(q.shape[1])) < 1e-12
+
+
+@pytest.mark.parametrize("shape,s_in,r", [
+    ((30, 28, 26, 24, 22), 12, 10),
+    ((100, 100, 100, 100), 40, 32),
+    ((200, 200, 200), 70, 64),
+])
+def test_hmt_one_call_cores_match_oracle(tsa, monkeypatch, shape, s_in, r):
+    d = len(shape)
+    cores, _, rd = _case(shape, s_in, None, r, seed=sum(shape) + r)
+    _, right = _dev_drms(tsa, shape, None, (r,) * (d - 1), None, rd)
+    hits = _one_call_ran(tsa, monkeypatch)
+    got = [np.asarray(c) for c in tsa.hmt_sketch(tsa.TensorTrain(cores), (r,) * (d - 1), drm=right).cores]
+    assert hits == [True]
+    want, _ = orc.general_sketch("tt", cores, None, rd, "hmt")
+    _close(got, want)
+
+
+def test_one_call_declines_what_it_does_not_cover(tsa, monkeypatch):
+    """Omega of different shapes per mode (no batched pseudo-inverse): the entry point answers 'unsupported', the
+    mode-by-mode path takes over, same cores as the oracle."""
+    shape, s_in = (24, 24, 24, 24), 10
+    l, r = (4, 6, 5), (8, 12, 10)
+    rng = np.random.default_rng(5)
+    cores = orc.random_tt(shape, s_in, rng)
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left = tsa.TensorTrainDRM(l, shape, False, seed=1, cores=[np.array(c) for c in ld.cores])
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=[np.array(c) for c in rd.cores])
+    hits = _one_call_ran(tsa, monkeypatch)
+    got = [np.asarray(c) for c in tsa.orthogonal_sketch(tsa.TensorTrain(cores), l, r, left_drm=left, right_drm=right).cores]
+    assert hits == [False]
+    want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+    _close(got, want)
+
+
+def test_one_call_rejection_repeats_on_the_robust_path(tsa, monkeypatch):
+    """An input of TT-rank 3 sketched with l = 8: Omega has rank 3, the normal equations are rejected on the device,
+    the deferred flag is read once and the sketch is repeated with the Jacobi pseudo-inverse -- the recovered tensor
+    is the input (sketch_dispatch.py:160-174 with numpy's pinv / qr in the reference)."""
+    shape, l, r = (20, 20, 20, 20), 8, 14
+    rng = np.random.default_rng(11)
+    cores = orc.random_tt(shape, 3, rng)
+    hits = _one_call_ran(tsa, monkeypatch)
+    X = tsa.TensorTrain(cores)
+    out = tsa.orthogonal_sketch(X, l, r, seed=4)
+    assert hits == [True]                          # it ran, and its result was thrown away
+    assert out.error(X) < 1e-10
+
+
+@pytest.mark.parametrize("m,K,n", [(10000, 100, 50), (37, 5, 3), (1000, 33, 64), (16, 4, 16), (4099, 130, 17), (200, 100, 50)])
+def test_tall_mul_with_gram(tsa, m, K, n):
+    """Y = A B and G = Y^T Y from one launch (tall_qr.hip) against numpy"""
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, as_dev
+    rng = np.random.default_rng(m + K + n)
+    A, B = rng.standard_normal((m, K)), rng.standard_normal((K, n))
+    dA, dB = as_dev(A), as_dev(B)
+    Y, G = DevArray.empty((m, n)), DevArray.empty((n, n))
+    P = ctypes.c_void_p
+    nat.call("ttsk_tall_mul", P(dA.ptr), m, K, P(dB.ptr), n, P(Y.ptr), P(G.ptr), 0)
+    want = A @ B
+    assert np.abs(Y.get() - want).max() <= 1e-13 * np.abs(want).max()
+    gw = want.T @ want
+    assert np.abs(G.get() - gw).max() <= 1e-13 * np.abs(gw).max()
+    Y2 = DevArray.empty((m, n))
+    nat.call("ttsk_tall_mul", P(dA.ptr), m, K, P(dB.ptr), n, P(Y2.ptr), None, 0)
+    assert np.array_equal(Y2.get(), Y.get())
+
+
+def test_one_call_with_the_fused_tall_kernels(tsa, monkeypatch):
+    """TTSK_ORTH_TALL=1 (product and Gram matrix of CholeskyQR2 in one launch): read once per process, so this runs
+    in a child interpreter; same cores as the default path to rounding."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, tt_sketch_amd as tsa
+from tt_sketch_amd import _native
+_native.call("ttsk_init", 0)
+rng = np.random.default_rng(0)
+shape, s, l, r = (60, 60, 60, 60), 30, 20, 40
+ranks = (1,) + (s,) * 3 + (1,)
+cores = [rng.standard_normal((ranks[i], shape[i], ranks[i + 1])) for i in range(4)]
+tt = tsa.orthogonal_sketch(tsa.TensorTrain(cores), (l,) * 3, (r,) * 3, seed=3)
+np.save(__import__("sys").argv[1], np.concatenate([np.asarray(c).ravel() for c in tt.cores]))
+"""
+    outs = []
+    for flag in ("0", "1"):
+        path = f"/tmp/ttsk_tall_{os.getpid()}_{flag}.npy"
+        env = dict(os.environ, TTSK_ORTH_TALL=flag)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)), timeout=300)
+        outs.append(np.load(path))
+        os.remove(path)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-10 * np.abs(outs[0]).max()
