@@ -320,7 +320,8 @@ int ttsk_deferred_status(int stream, int *host_flag);
  *   cores_out[d]  core mu (k_{mu-1}, n[mu], k_mu) with k_mu = lt[mu+1] (orthogonal) or rt[d-1-mu] (hmt), k_{-1} = k_{d-1} = 1
  *   omega_out     orthogonal: d - 1 matrices (lt[mu+1], rt[d-1-mu])
  * Verdicts deferred as in ttsk_orth_step (ttsk_deferred_status on `stream` afterwards).  TTSK_ERR_UNSUPPORTED: ranks
- * beyond 256, k_{mu-1} n[mu] < k_mu, Omega of different shapes or min(l, r) > 128, TTSK_FAST_SOLVES=0. */
+ * beyond 256, k_{mu-1} n[mu] < k_mu, TTSK_FAST_SOLVES=0.  (Omega of one shape with min(l, r) <= 128: the pseudo-inverses
+ * are batched launches; the sign reconstruction runs on stream + 1 and is joined back.) */
 int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
                         const double *const *X, const double *const *DL, const double *const *DR,
                         double *const *cores_out, double *const *omega_out, int stream);

@@ -103,9 +103,8 @@ def test_hmt_one_call_cores_match_oracle(tsa, monkeypatch, shape, s_in, r):
     _close(got, want)
 
 
-def test_one_call_declines_what_it_does_not_cover(tsa, monkeypatch):
-    """Omega of different shapes per mode (no batched pseudo-inverse): the entry point answers 'unsupported', the
-    mode-by-mode path takes over, same cores as the oracle."""
+def test_one_call_with_a_different_rank_in_every_mode(tsa, monkeypatch):
+    """Omega of different shapes per mode: pseudo-inverses one by one instead of batched, same cores as the oracle."""
     shape, s_in = (24, 24, 24, 24), 10
     l, r = (4, 6, 5), (8, 12, 10)
     rng = np.random.default_rng(5)
@@ -115,11 +114,38 @@ def test_one_call_declines_what_it_does_not_cover(tsa, monkeypatch):
     right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=[np.array(c) for c in rd.cores])
     hits = _one_call_ran(tsa, monkeypatch)
     got = [np.asarray(c) for c in tsa.orthogonal_sketch(tsa.TensorTrain(cores), l, r, left_drm=left, right_drm=right).cores]
-    assert hits == [False]
+    assert hits == [True]
     want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
     _close(got, want)
 
 
+@pytest.mark.parametrize("l,r", [(140, 150), (100, 200)])
+def test_one_call_ranks_beyond_128(tsa, monkeypatch, l, r):
+    """two-block Cholesky factors, sign reconstruction with its working copy in global memory (129 .. 256 columns)"""
+    shape, s_in = (160, 160, 160), 150
+    cores, ld, rd = _case(shape, s_in, l, r, seed=l + r)
+    left, right = _dev_drms(tsa, shape, (l,) * 2, (r,) * 2, ld, rd)
+    hits = _one_call_ran(tsa, monkeypatch)
+    got = [np.asarray(c) for c in tsa.orthogonal_sketch(tsa.TensorTrain(cores), (l,) * 2, (r,) * 2, left_drm=left, right_drm=right).cores]
+    assert hits == [True]
+    want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+    _close(got, want)
+    if r <= shape[0]:                         # (the first unfolding of hmt_sketch is n_0 x r)
+        got = [np.asarray(c) for c in tsa.hmt_sketch(tsa.TensorTrain(cores), (r,) * 2, drm=right).cores]
+        want, _ = orc.general_sketch("tt", cores, None, rd, "hmt")
+        _close(got, want)
+
+
+def test_one_call_declines_what_it_does_not_cover(tsa, monkeypatch):
+    """a right DRM that is not a tensor train: the mode-by-mode path, same tensor as the oracle's"""
+    shape, s_in, l, r = (16, 16, 16, 16), 3, 4, 9            # TT-rank 3 <= l: the sketch recovers the input
+    rng = np.random.default_rng(9)
+    cores = orc.random_tt(shape, s_in, rng)
+    hits = _one_call_ran(tsa, monkeypatch)
+    X = tsa.TensorTrain(cores)
+    out = tsa.orthogonal_sketch(X, l, r, seed=2, right_drm_type=tsa.DenseGaussianDRM)
+    assert hits == [False]
+    assert out.error(X) < 1e-10
 def test_one_call_rejection_repeats_on_the_robust_path(tsa, monkeypatch):
     """An input of TT-rank 3 sketched with l = 8: Omega has rank 3, the normal equations are rejected on the device,
     the deferred flag is read once and the sketch is repeated with the Jacobi pseudo-inverse -- the recovered tensor

@@ -1001,6 +1001,13 @@ static int pinv_cholesky_begin(const double *omega, int64_t l, int64_t r, double
     TTSK_HIP(hipMemcpyAsync(pinv, x1, (size_t)r * l * 8, hipMemcpyDeviceToDevice, st));
     return 1;
 }
+// one pseudo-inverse with a deferred verdict (ranks up to 256); ws: pinv_deferred_ws_elems doubles
+size_t pinv_deferred_ws_elems(int64_t l, int64_t r) { return pinv_ws_elems((int)(l < r ? l : r), l > r ? l : r); }
+int pinv_deferred(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st, double *ws, int *sticky)
+{
+    return pinv_cholesky_begin(omega, l, r, pinv, stream, st, ws, sticky);
+}
+
 // 1 = accepted (pinv is final), 0 = rejected
 static int pinv_cholesky_verdict(int64_t l, int64_t r, int stream, hipStream_t st)
 {
@@ -1041,7 +1048,9 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
     if ((rc = chol_inv_any(G, n, R1, nullptr, status, 1e-6, stream, st, cws, sticky))) return rc;       // kappa(A) up to ~1e6
     if ((rc = small_gemm(m, n, n, A, n, 1, R1, n, 1, Q1, stream))) return rc;            // Q1 = A R1^-1
     if ((rc = small_gemm(n, n, m, Q1, 1, n, Q1, n, 1, G, stream))) return rc;            // Q1^T Q1
-    if (unsigned_q && n <= CHOL_ONE) {
+    if (unsigned_q && n > CHOL_ONE) {
+        if ((rc = chol_inv_any(G, n, R2, nullptr, status + 1, 0.5, stream, st, cws, sticky))) return rc;    // must be ~identity
+    } else if (unsigned_q) {
         // R with positive diagonal only: the caller reconstructs the signs beside the critical path (qr_signs)
         static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
         hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, R2, (double *)nullptr,
@@ -1099,9 +1108,40 @@ __global__ __launch_bounds__(256) void qr_signs_kernel(const double *__restrict_
     for (int c = tid; c < n; c += 256) Sout[c] = S[c];
 }
 
-int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st)
+// the same for 128 < n <= 256: the working copy B (n x n) lives in global memory (L2), one column per step
+__global__ __launch_bounds__(1024) void qr_signs_global_kernel(const double *__restrict__ Qtop, int n, int square,
+                                                               const double *__restrict__ Sprev, int rows_per,
+                                                               double *__restrict__ B, double *__restrict__ Sout)
 {
-    if (n > CHOL_ONE) return 0;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 1024) B[e] = Qtop[e] * (Sprev ? Sprev[(e / n) / rows_per] : 1.0);
+    __threadfence_block();
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double piv = B[j * n + j];
+        double sgn = piv >= 0.0 ? -1.0 : 1.0;
+        if (square && j == n - 1) sgn = -sgn;
+        if (tid == 0) Sout[j] = sgn;
+        const double pinv = 1.0 / (piv - sgn);
+        const int rem = n - j - 1;
+        for (int e = tid; e < rem * rem; e += 1024) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            B[i * n + c] = fma(-B[i * n + j] * pinv, B[j * n + c], B[i * n + c]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// work: n * n doubles for n > 128 (may be nullptr otherwise)
+int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st, double *work)
+{
+    if (n > CHOL_ONE) {
+        if (n > CHOL_MAX || !work) return 0;
+        hipLaunchKernelGGL(qr_signs_global_kernel, dim3(1), dim3(1024), 0, st, Qtop, n, square, Sprev, rows_per, work, Sout);
+        TTSK_LAUNCH_CHECK();
+        return 1;
+    }
     static bool attr = false;
     if (!attr) {
         TTSK_HIP(hipFuncSetAttribute((const void *)qr_signs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));

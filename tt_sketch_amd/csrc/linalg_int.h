@@ -13,10 +13,15 @@ size_t qr_ws_elems(int64_t m, int n);    // doubles of workspace qr_cholesky nee
 // sticky: deferred verdict (no read-back; a rejection sets *sticky)
 int qr_cholesky(double *A, int64_t m, int64_t n, int stream, hipStream_t st, double *ws_in = nullptr, int *sticky = nullptr,
                 bool unsigned_q = false);
-// unsigned_q (n <= 128): Q comes out with the signs of CholeskyQR (R's diagonal positive) and the sign reconstruction is
+// unsigned_q: Q comes out with the signs of CholeskyQR (R's diagonal positive) and the sign reconstruction is
 // left to the caller (qr_signs on the top n x n block of Q, beside the critical path; apply_signs at the end);
 // return value 2 = the one-workgroup Householder kernel ran instead: Q carries LAPACK's signs already.
-int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st);
+int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int rows_per, double *Sout, hipStream_t st,
+             double *work = nullptr);            // work: n * n doubles when n > 128
+// pinv(Omega) (r x l) through the normal equations + one Newton-Schulz step, verdict deferred to *sticky; min(l, r) <= 256.
+// 1 = queued, 0 = outside the fast path
+size_t pinv_deferred_ws_elems(int64_t l, int64_t r);
+int pinv_deferred(const double *omega, int64_t l, int64_t r, double *pinv, int stream, hipStream_t st, double *ws, int *sticky);
 int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
                 const int *k1, hipStream_t st);
 constexpr int QR_CHOL_MAX_N = 256;       // largest column count of qr_cholesky

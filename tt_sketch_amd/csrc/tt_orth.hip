@@ -60,7 +60,7 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
         if (mu == d - 1) break;
         TTSK_ARG(DR[mu] && rt[mu + 1] >= 1 && (!orth || (DL[mu] && lt[mu + 1] >= 1 && omega_out[mu])), "ttsk_tt_orth_sketch: bad DRM core %d", mu);
         ok = ok && kk(mu) <= QR_CHOL_MAX_N && m >= kk(mu);
-        if (orth) ok = ok && lt[mu + 1] == lt[1] && rr(mu) == rr(0) && std::min(lt[1], rr(0)) <= 128;   // one batched pinv
+        if (orth) ok = ok && std::min(lt[mu + 1], rr(mu)) <= QR_CHOL_MAX_N;
         mmax = std::max(mmax, m);
         kmax = std::max(kmax, kk(mu));
     }
@@ -77,35 +77,54 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     CK(tt_chains(d, n, s, lt, rt, X, DL, DR, &ch, stream));
     // ---- workspace of this driver
     auto blk = [](size_t v) { return (v + 31) & ~(size_t)31; };
-    const size_t szP = orth ? blk((size_t)rr(0) * lt[1]) : 0, szW = orth ? blk((size_t)smax * lt[1]) : 0;
+    // (the d - 1 pseudo-inverses as batched launches when the Omega share one shape with min(l, r) <= 128)
+    bool one_shape = orth;
+    size_t pmax = 0, pws = 0;
+    int64_t lmax = 1;
+    for (int mu = 0; orth && mu < d - 1; ++mu) {
+        one_shape = one_shape && lt[mu + 1] == lt[1] && rr(mu) == rr(0) && s[mu + 1] == s[1];
+        pmax = std::max(pmax, (size_t)rr(mu) * lt[mu + 1]);
+        pws = std::max(pws, pinv_deferred_ws_elems(lt[mu + 1], rr(mu)));
+        lmax = std::max(lmax, lt[mu + 1]);
+    }
+    one_shape = one_shape && std::min(lt[1], rr(0)) <= 128;
+    const size_t szP = orth ? blk(pmax) : 0, szW = orth ? blk((size_t)smax * lmax) : 0;
     const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax);
     const size_t szQ = blk(std::max(qr_ws_elems(mmax, (int)kmax), qr_mul_ws_elems(mmax, (int)kmax)));
     static const int tall_on = [] { const char *e = getenv("TTSK_ORTH_TALL"); return e ? atoi(e) : 0; }();   // (tall_qr.hip: not faster yet)
-    const size_t szS = blk((size_t)kmax);
-    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW + szS) + 2 * szL + szT + szQ) * 8);
+    const size_t szS = blk((size_t)kmax), szSW = kmax > 128 ? blk((size_t)kmax * kmax) : 0, szPW = one_shape ? 0 : blk(pws);
+    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW + szS) + 2 * szL + szT + szQ + szSW + szPW) * 8);
     if (!ws) return TTSK_ERR_HIP;
     double *P0 = ws, *W0 = P0 + (size_t)(d - 1) * szP, *Lb = W0 + (size_t)(d - 1) * szW, *T = Lb + 2 * szL, *qws = T + szT, *Sb = qws + szQ;
+    double *signs_work = szSW ? Sb + (size_t)(d - 1) * szS : nullptr, *pinv_work = Sb + (size_t)(d - 1) * szS + szSW;
     // ---- 2. W_mu = R_mu Omega_mu^+  (s[mu+1] x l)
     std::vector<const double *> W(d - 1);
     if (orth) {
         const double *om[SK_MAXB];
         double *pv[SK_MAXB];
         for (int mu = 0; mu < d - 1; ++mu) { om[mu] = omega_out[mu]; pv[mu] = P0 + (size_t)mu * szP; }
-        CK(ttsk_pinv_batch_deferred(d - 1, om, lt[1], rr(0), pv, stream));
-        bool same = true;
-        for (int mu = 1; mu < d - 1; ++mu) same = same && s[mu + 1] == s[1];
+        if (one_shape) {
+            CK(ttsk_pinv_batch_deferred(d - 1, om, lt[1], rr(0), pv, stream));
+        } else {
+            for (int mu = 0; mu < d - 1; ++mu) {
+                rc = pinv_deferred(om[mu], lt[mu + 1], rr(mu), pv[mu], stream, st, pinv_work, sticky);
+                if (rc < 0) return rc;
+                if (rc == 0) { set_error("ttsk_tt_orth_sketch: pseudo-inverse outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
+            }
+        }
         const double *A[SK_MAXB], *B[SK_MAXB];
         double *C[SK_MAXB];
         for (int mu = 0; mu < d - 1; ++mu) { A[mu] = ch.Rc[d - 2 - mu]; B[mu] = pv[mu]; C[mu] = W0 + (size_t)mu * szW; W[mu] = C[mu]; }
         int done = 0;
-        if (same) {
+        if (one_shape) {
             ttsk_gemm_desc g{};
             g.batch = 1; g.M = s[1]; g.N = lt[1]; g.Ko = 1; g.Ki = rr(0);
             g.a_m = rr(0); g.a_ki = 1; g.b_ki = lt[1]; g.b_n = 1; g.c_m = lt[1]; g.c_n = 1; g.alpha = 1.0;
             CK(done = small_try_batch(g, d - 1, A, B, C, stream, st));
         }
         if (!done)
-            for (int mu = 0; mu < d - 1; ++mu) CK(gemm2(s[mu + 1], lt[1], rr(0), A[mu], rr(0), 1, B[mu], lt[1], 1, C[mu], stream));
+            for (int mu = 0; mu < d - 1; ++mu)
+                CK(gemm2(s[mu + 1], lt[mu + 1], rr(mu), A[mu], rr(mu), 1, B[mu], lt[mu + 1], 1, C[mu], stream));
     } else {
         for (int mu = 0; mu < d - 1; ++mu) W[mu] = ch.Rc[d - 2 - mu];
     }
@@ -115,7 +134,7 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     // flips -- and the sign reconstruction of every mode (an n-step elimination in one workgroup) runs on the helper
     // stream beside the next mode's products.  One pass over the cores at the end applies S_{mu-1} (rows) and S_mu (columns).
     static const int signs_beside = [] { const char *e = getenv("TTSK_ORTH_SIGNS_BESIDE"); return e ? atoi(e) : 1; }();
-    bool beside = signs_beside && kmax <= 128;
+    bool beside = signs_beside && kmax <= QR_CHOL_MAX_N;
     for (int mu = 1; mu < d - 1; ++mu) beside = beside && kk(mu - 1) * n[mu] >= 2 * kk(mu);   // (the one-workgroup Householder QR of a nearly square unfolding signs its Q itself: only mode 0 may take it)
     const int aux = (stream + 1) % TTSK_NUM_STREAMS;
     TTSK_STREAM(st_aux, aux);
@@ -161,7 +180,7 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
         if (beside && rc != 2) {
             double *Sm = Sb + (size_t)mu * szS;
             CK(ttsk_stream_wait(aux, stream));                                     // Q~ is there
-            CK(qr_signs(Q, (int)k, m == k ? 1 : 0, mu > 0 ? Sg[mu - 1] : nullptr, (int)nn, Sm, st_aux));
+            CK(qr_signs(Q, (int)k, m == k ? 1 : 0, mu > 0 ? Sg[mu - 1] : nullptr, (int)nn, Sm, st_aux, signs_work));
             Sg[mu] = Sm;
         }
         // next chain matrix Ln[p', q'] = sum_{(q,i)} T[(q,i), p'] Q[(q,i), q']
