@@ -821,7 +821,7 @@ def bench_c3_solves(args, job, reps=7):
         out[name] = dict(ms=med, best_ms=best, algorithmic_gflop=gf,
                          roofline=dict(bound="mfma", achieved=gf / med, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s", frac=gf / med / PEAK_F64_MFMA_TF,
                                        traffic=None, what="sketch products + pinv-apply + thin QR flops / wall time of one API call incl. DRM "
-                                                          "sampling: a chain of ~100 dependent launches on 10^4-row operands, latency-bound"))
+                                                          "sampling: a chain of ~80 dependent launches on 10^4-row operands (ttsk_tt_orth_sketch), latency-bound"))
     if not args.no_cpu and job.world == 1 and job.rank == 0:
         import __graft_entry__ as ge
         ge.build_oracle()

@@ -22,7 +22,16 @@ for c in c2 c4 ref150; do
   run pmc_r03f_$c --kernel-trace --pmc FETCH_SIZE -d $R/pmc_r03f_$c -o p --output-format csv -- python3 $B --config $c --steps 5 --warmup 2 --no-cpu
   run pmc_r03w_$c --kernel-trace --pmc WRITE_SIZE -d $R/pmc_r03w_$c -o p --output-format csv -- python3 $B --config $c --steps 5 --warmup 2 --no-cpu
 done
+# 4. the sequential variants at C3: kernel stats and the launch timeline of the last call
+for w in orth hmt; do
+  run prof_r03_$w --kernel-trace --stats -d $R/prof_r03_$w -o bench --output-format csv -- python3 $GRAFT_REPO_ROOT/profiles/scripts/orth_bench.py $w
+  tail -1 $R/prof_r03_$w.log
+done
 cd $GRAFT_REPO_ROOT
+for w in orth hmt; do
+  python3 profiles/scripts/timeline.py gpurun_out/prof_r03_$w/bench_kernel_trace.csv 13 > gpurun_out/r03_${w}_timeline.txt 2>&1
+  cp gpurun_out/prof_r03_$w/bench_kernel_stats.csv gpurun_out/r03_${w}_kernel_stats.csv
+done
 python3 profiles/by_grid.py gpurun_out/prof_r03d/bench_kernel_trace.csv gpurun_out/r03_kernel_by_grid.csv > gpurun_out/r03_by_grid.txt 2>&1
 python3 profiles/by_grid.py gpurun_out/prof_r03s/bench_kernel_trace.csv gpurun_out/r03_kernel_by_grid_single_stream.csv > gpurun_out/r03_by_grid_single.txt 2>&1
 rm -f gpurun_out/r03_traffic.json
