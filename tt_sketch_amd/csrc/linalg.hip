@@ -474,7 +474,9 @@ __device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, do
 // and writes Rinv with its columns scaled by them: three launches of qr_cholesky in one.
 // sticky (optional): set to 1 on rejection, never cleared here (deferred verdicts: ttsk_orth_step);
 // pminmax (optional): smallest / largest pivot, for callers that combine several blocks (chol_inv_any).
-__global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
+// Launched with 256 threads, or with 1024 (n <= 64, chol_threads()): the extra twelve waves take part in the recurrence
+// only -- one row per 16-lane group instead of four, twelve more waves to hide the LDS round trips behind -- and leave.
+__global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
                                                        double *__restrict__ Ginv, int *__restrict__ status,
                                                        double cond_tol, int *__restrict__ sticky, double *__restrict__ pminmax,
                                                        const double *__restrict__ Qtop = nullptr, int square = 0, int expand = 1)
@@ -488,7 +490,9 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     status += blockIdx.x;
     double *A = sm;
     double *xd = sm + n * ld;
-    for (int e = tid; e < n * n; e += 256) A[(e / n) * ld + e % n] = G[e];
+    const int nthr = blockDim.x;
+    const bool core = tid < 256;                       // the threads that run every phase
+    for (int e = tid; e < n * n; e += nthr) A[(e / n) * ld + e % n] = G[e];
     __syncthreads();
     // Unscaled right-looking recurrence: row j keeps r_j R[j][:] (r_j^2 = pivot) until the end, the trailing update
     // divides by the pivot instead, every thread reads the pivots itself.  TWO columns per barrier: the pivot of
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
     // (History at n = 50: three barriers per column 75 us of 118; one per column 55 k cycles; two columns 42 k.)
     int bad = 0;
     double pmin = 1e300, pmax = 0.0;                 // pivots r_j^2: the square root is not needed in the loop
-    const int ti = tid >> 4, tc = tid & 15;
+    const int ti = tid >> 4, tc = tid & 15, nrow = nthr >> 4;
     // hardware reciprocal + two Newton steps (a full division is ~4x the instructions, on the critical path)
     auto rcp2 = [](double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); };
     __shared__ double shadow[2 * 128];
@@ -509,28 +513,32 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         // factor's inverse is I - Phi(E) (Phi: strict upper triangle + half the diagonal) to within n |E|^2 < 1e-17:
         // no recurrence at all (n / 2 steps of ~1600 cycles otherwise).
         double em = 0.0;
-        for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, c = e - i * n;
-            em = fmax(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
+        if (core) {
+            for (int e = tid; e < n * n; e += 256) {
+                const int i = e / n, c = e - i * n;
+                em = fmax(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
+            }
+            em = fmax(em, jac_dpp<0xB1>(em));
+            em = fmax(em, jac_dpp<0x4E>(em));
+            if ((tid & 3) == 0) shadow[tid >> 2] = em;
         }
-        em = fmax(em, jac_dpp<0xB1>(em));
-        em = fmax(em, jac_dpp<0x4E>(em));
-        if ((tid & 3) == 0) shadow[tid >> 2] = em;
         __syncthreads();
         em = 0.0;
         for (int k = 0; k < 64; ++k) em = fmax(em, shadow[k]);
         __syncthreads();
         if (em * n <= 1e-8) {                                   // NaN compares false: the recurrence below rejects it
-            for (int e = tid; e < n * n; e += 256) {
-                const int i = e / n, c = e - i * n;
-                if (i < c) A[c * ld + i] = -A[i * ld + c];      // X[i][c] lives at A[c][i]
-                else if (i == c) xd[c] = 1.0 - 0.5 * (A[i * ld + i] - 1.0);
-            }
+            if (core)
+                for (int e = tid; e < n * n; e += 256) {
+                    const int i = e / n, c = e - i * n;
+                    if (i < c) A[c * ld + i] = -A[i * ld + c];      // X[i][c] lives at A[c][i]
+                    else if (i == c) xd[c] = 1.0 - 0.5 * (A[i * ld + i] - 1.0);
+                }
             if (tid == 0) status[0] = 0;
             __syncthreads();
             expanded = true;
         }
     }
+    if (expanded && !core) return;
     if (!expanded) {
     for (; j + 1 < n; j += 2) {
         const double *r0 = A + j * ld, *r1 = A + (j + 1) * ld;
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
         const double pi1 = rcp2(p1);
         pmin = fmin(pmin, fmin(p0, p1));
         pmax = fmax(pmax, fmax(p0, p1));
-        for (int i = j + 2 + ti; i < n; i += 16) {
+        for (int i = j + 2 + ti; i < n; i += nrow) {
             const double a0 = r0[i], a1 = fma(-g, a0, r1[i]);  // A[j][i] and A[j+1][i] after step j
             const double f0 = a0 * pi0, f1 = a1 * pi1;
             for (int c = i + tc; c < n; c += 16) {
@@ -552,11 +560,12 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *__restrict_
             }
         }
         double *sh = shadow + ((j >> 1) & 1) * 128;
-        for (int c = j + 1 + tid; c < n; c += 256) sh[c] = fma(-g, r0[c], r1[c]);
+        for (int c = j + 1 + tid; c < n; c += nthr) sh[c] = fma(-g, r0[c], r1[c]);
         __syncthreads();
-        for (int c = j + 1 + tid; c < n; c += 256) A[(j + 1) * ld + c] = sh[c];
+        for (int c = j + 1 + tid; c < n; c += nthr) A[(j + 1) * ld + c] = sh[c];
     }
     __syncthreads();
+    if (!core) return;
     if (j < n) {                                               // odd n: the last pivot
         double piv = A[j * ld + j];
         if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
@@ -828,6 +837,12 @@ static int small_gemm(int64_t M, int64_t N, int64_t K, const double *A, int64_t 
     return ttsk_gemm(&d, A, B, C, nullptr, stream);
 }
 
+static unsigned chol_threads(int n)
+{
+    static const int wide = [] { const char *e = getenv("TTSK_CHOL_WIDE"); return e ? atoi(e) : 1; }();
+    return (wide && n <= 64) ? 1024u : 256u;
+}
+
 static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st,
                        int *sticky = nullptr, double *pminmax = nullptr, int count = 1)
 {
@@ -837,7 +852,7 @@ static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *
         TTSK_HIP(hipFuncSetAttribute((const void *)hh_sign_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)count), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status,
+    hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)count), dim3(chol_threads(n)), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status,
                        cond_tol, sticky, pminmax);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
