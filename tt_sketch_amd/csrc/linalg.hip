@@ -467,7 +467,7 @@ namespace ttsk {
 
 // G (n x n symmetric, row-major) = R^T R; Rinv = R^-1 (upper triangular, dense n x n) and optionally
 // Ginv = Rinv Rinv^T = G^-1.  status[0] = 0 ok, 1 rejected.
-__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid);
+__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid, int nthr = 256);
 
 // Qtop (optional, n <= CHOL_SIGN_MAX): the call is the SECOND factorisation of CholeskyQR2 -- the kernel goes on to form
 // the top n x n block of Q = Qtop R^-1 in LDS, reconstructs LAPACK's Householder column signs from it (hh_signs_lds)
@@ -695,11 +695,11 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
 // the modified LU of the top n x n block of Q (Ballard et al., "Reconstructing Householder vectors
 // from TSQR"): S_j = -sgn(pivot_j); for a square matrix the last reflector is the identity.
 // Scales the columns of Rinv (n x n) by S in place.
-__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid)
+__device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, double *shadow, int tid, int nthr)
 {
     // only the signs are needed: every thread derives the modified pivots itself and the trailing update uses the
     // unscaled columns; two columns per barrier as in chol_inv_kernel (row j + 1 after step j through a shadow row)
-    const int ti = tid >> 4, tc = tid & 15;
+    const int ti = tid >> 4, tc = tid & 15, nrow = nthr >> 4;          // (every thread of the workgroup calls this: barriers inside)
     int j = 0;
     for (; j + 1 < n; j += 2) {
         const double *b0 = B + j * ld, *b1 = B + (j + 1) * ld;
@@ -711,7 +711,7 @@ __device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, do
         if (square && j + 1 == n - 1) sgn1 = -sgn1;
         const double pinv1 = 1.0 / (piv1 - sgn1);
         if (tid == 0) { S[j] = sgn0; S[j + 1] = sgn1; }
-        for (int i = j + 2 + ti; i < n; i += 16) {
+        for (int i = j + 2 + ti; i < n; i += nrow) {
             const double f0 = B[i * ld + j] * pinv0;
             const double f1 = fma(-f0, b0[j + 1], B[i * ld + j + 1]) * pinv1;
             for (int c = j + 2 + tc; c < n; c += 16) {
@@ -720,9 +720,9 @@ __device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, do
             }
         }
         double *sh = shadow + ((j >> 1) & 1) * 128;
-        for (int c = j + 2 + tid; c < n; c += 256) sh[c] = fma(-g, b0[c], b1[c]);
+        for (int c = j + 2 + tid; c < n; c += nthr) sh[c] = fma(-g, b0[c], b1[c]);
         __syncthreads();
-        for (int c = j + 2 + tid; c < n; c += 256) B[(j + 1) * ld + c] = sh[c];
+        for (int c = j + 2 + tid; c < n; c += nthr) B[(j + 1) * ld + c] = sh[c];
     }
     __syncthreads();
     if (j < n) {                                                         // odd n: the last pivot
@@ -840,7 +840,7 @@ static int small_gemm(int64_t M, int64_t N, int64_t K, const double *A, int64_t 
 static unsigned chol_threads(int n)
 {
     static const int wide = [] { const char *e = getenv("TTSK_CHOL_WIDE"); return e ? atoi(e) : 1; }();
-    return (wide && n <= 64) ? 1024u : 256u;
+    return (wide && n <= (wide == 1 ? 128 : 64)) ? 1024u : 256u;
 }
 
 static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st,
@@ -1107,20 +1107,21 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
 // The Householder column signs of Q = D Qc (Qc: top n x n block of a CholeskyQR factor with positive diagonal R, D a
 // +-1 scaling of its rows given per group of `rows_per` rows -- the signs of the previous mode's factor, which scale the
 // rows of this mode's unfolding): S[c] for the caller to apply whenever it likes.  One workgroup.
-__global__ __launch_bounds__(256) void qr_signs_kernel(const double *__restrict__ Qtop, int n, int square,
+__global__ __launch_bounds__(1024) void qr_signs_kernel(const double *__restrict__ Qtop, int n, int square,
                                                        const double *__restrict__ Sprev, int rows_per, double *__restrict__ Sout)
 {
     extern __shared__ double sm[];
     const int ld = n + 1, tid = threadIdx.x;
     double *B = sm, *S = sm + n * ld;
     __shared__ double shadow[2 * 128];
-    for (int e = tid; e < n * n; e += 256) {
+    const int nthr = blockDim.x;
+    for (int e = tid; e < n * n; e += nthr) {
         const int r = e / n;
         B[r * ld + e % n] = Qtop[e] * (Sprev ? Sprev[r / rows_per] : 1.0);
     }
     __syncthreads();
-    hh_signs_lds(B, n, ld, square, S, shadow, tid);
-    for (int c = tid; c < n; c += 256) Sout[c] = S[c];
+    hh_signs_lds(B, n, ld, square, S, shadow, tid, nthr);
+    for (int c = tid; c < n; c += nthr) Sout[c] = S[c];
 }
 
 // the same for 128 < n <= 256: the working copy B (n x n) lives in global memory (L2), one column per step
@@ -1162,7 +1163,7 @@ int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int row
         TTSK_HIP(hipFuncSetAttribute((const void *)qr_signs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(qr_signs_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n, square, Sprev, rows_per, Sout);
+    hipLaunchKernelGGL(qr_signs_kernel, dim3(1), dim3(chol_threads(n)), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n, square, Sprev, rows_per, Sout);
     TTSK_LAUNCH_CHECK();
     return 1;
 }
