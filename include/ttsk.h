@@ -326,6 +326,18 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
                         const double *const *X, const double *const *DL, const double *const *DR,
                         double *const *cores_out, double *const *omega_out, int stream);
 
+/* ttsk_pinv for `count` (<= 32) matrices of ONE shape (l, r), min(l, r) <= 128: every stage of the fast attempt one batched
+ * launch, the robust kernel queued behind it per matrix with that matrix's verdict as predicate; no read-back (utils.py:98-109
+ * for the d - 1 Omega of an assembly).  TTSK_ERR_UNSUPPORTED outside that cover. */
+int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream);
+/* assemble_sketched_tt (sketch.py:400-443) as one call: direction 0 ("right") C_mu = Psi_mu pinv(Omega_mu), mu < d - 1,
+ * C_{d-1} = Psi_{d-1}; direction 1 ("left") C_0 = Psi_0, C_{mu+1} = pinv(Omega_mu) Psi_{mu+1}.  lr / rr: the d - 1 sketch
+ * ranks; psi[mu] (lr[mu-1], n[mu], rr[mu]) contiguous; omega[mu] (lr[mu], rr[mu]); work[mu]: rr[mu] * lr[mu] doubles that
+ * receive pinv(Omega_mu).  Pair mu runs on stream (stream + mu) mod TTSK_NUM_STREAMS with ttsk_pinv's robust fallback
+ * queued behind the fast attempt (no read-back); all streams are joined into `stream` before the call returns. */
+int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *rr, const double *const *dev_psi,
+                     const double *const *dev_omega, double *const *dev_cores_out, double *const *dev_work, int direction,
+                     int stream);
 /* Y (m, n) = A (m, K) B (K, n), all contiguous row-major, and -- G != NULL -- G (n, n) = Y^T Y from the same launch
  * (the tile of Y is both MFMA operands of its own Gram product): the "product, then Gram matrix" pairs of CholeskyQR2
  * inside ttsk_tt_orth_sketch (sketch_dispatch.py:160-174).  n <= 64, K n within the LDS; else TTSK_ERR_UNSUPPORTED. */

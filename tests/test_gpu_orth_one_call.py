@@ -205,3 +205,46 @@ np.save(__import__("sys").argv[1], np.concatenate([np.asarray(c).ravel() for c i
         outs.append(np.load(path))
         os.remove(path)
     assert np.abs(outs[0] - outs[1]).max() <= 1e-10 * np.abs(outs[0]).max()
+
+
+def test_pinv_batch_mixes_accepted_and_rejected_matrices(tsa):
+    """ttsk_pinv_batch: five 12 x 30 matrices in one set of launches, two of them rank deficient (the Jacobi kernel takes
+    over for exactly those, through its predicate) -- numpy.linalg.pinv's result for each (utils.py:98-109)."""
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, as_dev
+    rng = np.random.default_rng(3)
+    l, r = 12, 30
+    mats = [rng.standard_normal((l, r)) for _ in range(5)]
+    mats[1] = rng.standard_normal((l, 4)) @ rng.standard_normal((4, r))          # rank 4
+    mats[3][5] = mats[3][2] * 0.5 - mats[3][7]                                     # rank 11
+    P = ctypes.c_void_p
+    for transposed in (False, True):
+        hs = [m.T.copy() if transposed else m for m in mats]
+        ds = [as_dev(h) for h in hs]
+        outs = [DevArray.empty(h.T.shape) for h in hs]
+        nat.call("ttsk_pinv_batch", 5, (P * 5)(*[x.ptr for x in ds]), hs[0].shape[0], hs[0].shape[1], (P * 5)(*[o.ptr for o in outs]), 0)
+        for k, (h, o) in enumerate(zip(hs, outs)):
+            want = np.linalg.pinv(h, rcond=16 * np.finfo(float).eps * np.sqrt(max(h.shape)))
+            assert np.abs(o.get() - want).max() <= 1e-11 * np.abs(want).max(), (transposed, k)
+
+
+@pytest.mark.parametrize("direction", ["right", "left"])
+@pytest.mark.parametrize("ranks", [((6, 6, 6), (9, 9, 9)), ((4, 7, 5), (8, 11, 6))])
+def test_assemble_one_call_matches_the_pair_by_pair_path(tsa, monkeypatch, direction, ranks):
+    """ttsk_tt_assemble (batched pseudo-inverses when the Omega share a shape, pair by pair otherwise) against
+    assemble_sketched_tt's own loop and against numpy (sketch.py:400-443)."""
+    from tt_sketch_amd.sketch import assemble_sketched_tt
+    shape = (14, 15, 16, 17)
+    lr, rr = ranks
+    if direction == "left":
+        lr, rr = rr, lr
+    rng = np.random.default_rng(21)
+    X = tsa.TensorTrain(orc.random_tt(shape, 3, rng))
+    stt = tsa.stream_sketch(X, lr, rr, seed=5)
+    one = [np.asarray(c) for c in assemble_sketched_tt(stt.sketch_ if hasattr(stt, "sketch_") else stt.sketch, direction=direction)]
+    monkeypatch.setenv("TTSK_ASSEMBLE_ONE_CALL", "0")
+    pairs = [np.asarray(c) for c in assemble_sketched_tt(stt.sketch_ if hasattr(stt, "sketch_") else stt.sketch, direction=direction)]
+    for a, b in zip(one, pairs):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    rec = tsa.TensorTrain(one)
+    assert rec.error(X) < 1e-9

@@ -1338,6 +1338,71 @@ int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, d
     return TTSK_OK;
 }
 
+// The pseudo-inverses of `count` matrices of ONE shape with ttsk_pinv's contract (gelsd's truncation on rejection), every
+// stage of the fast attempt ONE batched launch and the Jacobi kernels queued behind it, each with its own matrix's verdict
+// as predicate: 3 + count launches instead of 6 count (assemble_sketched_tt: the launches are what its d - 1 independent
+// pseudo-inverses cost).  No read-back.  TTSK_ERR_UNSUPPORTED: min(l, r) > 128, count > 32, TTSK_FAST_SOLVES=0.
+int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(count >= 1 && count <= SK_MAXB && dev_omegas && dev_pinvs && l >= 1 && r >= 1, "ttsk_pinv_batch: bad argument");
+    const int n = (int)(l < r ? l : r);
+    static int *vd = [] {                              // verdicts outside the scratch arena (the Jacobi kernel works there)
+        int *q = nullptr;
+        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * SK_MAXB * sizeof(int)) != hipSuccess) q = nullptr;
+        return q;
+    }();
+    if (!fast_solves() || !vd || n > CHOL_ONE || pinv_rcond(l, r, -1.0) > 1e-4) {
+        set_error("ttsk_pinv_batch: (%lld x %lld) is outside the batched fast path", (long long)l, (long long)r);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    int *status = vd + (size_t)stream * SK_MAXB;
+    const int transposed = r >= l;
+    const int64_t mW = transposed ? r : l, nW = transposed ? l : r;
+    const size_t jws = (size_t)(mW * nW + nW * nW) + 1;
+    double *ws = (double *)scratch(stream, SCRATCH_MISC, (jws + (size_t)count * 3 * n * n + 64) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *G0 = ws + jws, *R0 = G0 + (size_t)count * n * n, *I0 = R0 + (size_t)count * n * n;
+    const double *Om[SK_MAXB], *cI[SK_MAXB];
+    double *G[SK_MAXB], *P[SK_MAXB];
+    for (int b = 0; b < count; ++b) {
+        TTSK_ARG(dev_omegas[b] && dev_pinvs[b], "ttsk_pinv_batch: NULL matrix %d", b);
+        Om[b] = dev_omegas[b]; P[b] = dev_pinvs[b];
+        G[b] = G0 + (size_t)b * n * n; cI[b] = I0 + (size_t)b * n * n;
+    }
+    auto desc = [](int64_t M, int64_t N, int64_t K, int64_t a_m, int64_t a_k, int64_t b_k, int64_t b_n) {
+        ttsk_gemm_desc d{};
+        d.batch = 1; d.M = M; d.N = N; d.Ko = 1; d.Ki = K;
+        d.a_m = a_m; d.a_ki = a_k; d.b_ki = b_k; d.b_n = b_n; d.c_m = N; d.c_n = 1;
+        d.alpha = 1.0;
+        return d;
+    };
+    int rc;
+#define TTSK_PB(call) do { rc = (call); if (rc < 0) return rc; if (rc == 0) { set_error("ttsk_pinv_batch: product outside the small kernel"); return TTSK_ERR_UNSUPPORTED; } } while (0)
+    if (l <= r) {
+        TTSK_PB(small_try_batch(desc(l, l, r, r, 1, 1, r), count, Om, Om, G, stream, st));                  // G = Omega Omega^T
+        if ((rc = launch_chol(G0, n, R0, I0, status, 1.0 / 300.0, st, nullptr, nullptr, count))) return rc;
+        TTSK_PB(small_try_batch(desc(r, l, l, 1, r, l, 1), count, Om, cI, P, stream, st));                  // X = Omega^T G^-1
+    } else {
+        TTSK_PB(small_try_batch(desc(r, r, l, 1, r, r, 1), count, Om, Om, G, stream, st));                  // G = Omega^T Omega
+        if ((rc = launch_chol(G0, n, R0, I0, status, 1.0 / 300.0, st, nullptr, nullptr, count))) return rc;
+        TTSK_PB(small_try_batch(desc(r, l, r, r, 1, 1, r), count, cI, Om, P, stream, st));                  // X = G^-1 Omega^T
+    }
+#undef TTSK_PB
+    // rejected ones: the Jacobi kernel on the untouched input (it leaves at once where the attempt was accepted)
+    size_t jl = 0;
+    const int jm = jacobi_lds_mode(mW, nW, &jl);
+    if (jm < 0) return TTSK_ERR_HIP;
+    auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
+    const double rcond = pinv_rcond(l, r, -1.0);
+    for (int b = 0; b < count; ++b) {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, Om[b], l, r, transposed, ws, ws + mW * nW, rcond, P[b], (int *)nullptr,
+                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (const int *)(status + b));
+        TTSK_LAUNCH_CHECK();
+    }
+    return TTSK_OK;
+}
+
 int ttsk_pinv(const double *dev_omega, int64_t l, int64_t r, double rcond, double *dev_pinv,
               int *host_rank, int stream)
 {

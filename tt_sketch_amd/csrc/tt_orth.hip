@@ -37,6 +37,7 @@ int gemm2(int64_t M, int64_t N, int64_t K, const double *A, int64_t a_m, int64_t
 extern "C" {
 
 int ttsk_pinv_batch_deferred(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream);
+int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64_t r, double *const *dev_pinvs, int stream);
 
 int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
                         const double *const *X, const double *const *DL, const double *const *DR,
@@ -193,6 +194,68 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
             for (int mu = 0; mu < d - 1; ++mu) CK(fix_core(mu));
         CK(fix_core(d - 1));
         CK(ttsk_stream_wait(stream, aux));
+    }
+#undef CK
+    return TTSK_OK;
+}
+
+// assemble_sketched_tt (sketch.py:400-443) as ONE call: C_mu = Psi_mu pinv(Omega_mu) ("right", direction = 0) or
+// pinv(Omega_{mu-1}) Psi_mu ("left", direction = 1).  The d - 1 (pseudo-inverse, product) pairs are independent: pair k
+// runs on library stream k mod nstreams -- fast attempt, the Jacobi kernel queued behind it with the attempt's verdict
+// as its predicate (ttsk_pinv_begin / ttsk_pinv_end without a rank read-back), then the product -- and every stream is
+// joined into `stream` before the call returns.  No host synchronisation.
+//   psi[mu]     (l_{mu-1}, n[mu], r_mu) contiguous, l_{-1} = r_{d-1} = 1;   omega[mu] (l_mu, r_mu), mu < d - 1
+//   cores_out   right: (l_{mu-1}, n, l_mu), last = psi[d-1];  left: (r_{mu-1}, n, r_mu), first = psi[0]
+//   work[k]     (r_k, l_k) doubles each: the pseudo-inverses (caller's, so that they outlive the call)
+int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *rr, const double *const *psi,
+                     const double *const *omega, double *const *cores_out, double *const *work, int direction, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(d >= 2 && d <= 64 && n && lr && rr && psi && omega && cores_out && work && (direction == 0 || direction == 1),
+             "ttsk_tt_assemble: bad argument");
+    int rc;
+#define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
+    const int nstreams = std::min(d - 1, TTSK_NUM_STREAMS);
+    // Omega of one shape: the pseudo-inverses as batched launches on `stream`, then only the products are dealt out
+    bool batched = d - 1 >= 2 && d - 1 <= SK_MAXB;
+    for (int k = 0; k < d - 1; ++k) {
+        TTSK_ARG(omega[k] && work[k] && lr[k] >= 1 && rr[k] >= 1, "ttsk_tt_assemble: bad Omega %d", k);
+        batched = batched && lr[k] == lr[0] && rr[k] == rr[0];
+    }
+    static const int batch_on = [] { const char *e = getenv("TTSK_ASSEMBLE_BATCH"); return e ? atoi(e) : 1; }();
+    if (batched && batch_on) {
+        rc = ttsk_pinv_batch(d - 1, omega, lr[0], rr[0], work, stream);
+        if (rc == TTSK_ERR_UNSUPPORTED) batched = false;
+        else if (rc < 0) return rc;
+    } else {
+        batched = false;
+    }
+    for (int k = 0; k < d - 1; ++k) {
+        const int q = (stream + k) % TTSK_NUM_STREAMS;
+        if (k < nstreams && q != stream) CK(ttsk_stream_wait(q, stream));        // fork
+        if (!batched) {
+            CK(ttsk_pinv_begin(omega[k], lr[k], rr[k], -1.0, work[k], q));
+            CK(ttsk_pinv_end(omega[k], lr[k], rr[k], -1.0, work[k], nullptr, q));
+        }
+        if (direction == 0) {
+            // C_k[(a, i), b] = sum_c Psi_k[(a, i), c] P_k[c, b]
+            const int64_t m = (k ? lr[k - 1] : 1) * n[k];
+            TTSK_ARG(psi[k] && cores_out[k], "ttsk_tt_assemble: NULL core %d", k);
+            CK(gemm2(m, lr[k], rr[k], psi[k], rr[k], 1, work[k], lr[k], 1, cores_out[k], q));
+        } else {
+            // C_{k+1}[c, (i, b)] = sum_a P_k[c, a] Psi_{k+1}[a, (i, b)]
+            const int64_t cols = n[k + 1] * (k + 1 < d - 1 ? rr[k + 1] : 1);
+            TTSK_ARG(psi[k + 1] && cores_out[k + 1], "ttsk_tt_assemble: NULL core %d", k + 1);
+            CK(gemm2(rr[k], cols, lr[k], work[k], lr[k], 1, psi[k + 1], cols, 1, cores_out[k + 1], q));
+        }
+    }
+    const int e = direction == 0 ? d - 1 : 0;                                   // the core that is copied
+    TTSK_ARG(psi[e] && cores_out[e], "ttsk_tt_assemble: NULL core %d", e);
+    const int64_t sz = direction == 0 ? lr[d - 2] * n[d - 1] : n[0] * rr[0];
+    if (cores_out[e] != psi[e]) TTSK_HIP(hipMemcpyAsync(cores_out[e], psi[e], (size_t)sz * 8, hipMemcpyDeviceToDevice, st));
+    for (int k = 0; k < nstreams; ++k) {
+        const int q = (stream + k) % TTSK_NUM_STREAMS;
+        if (q != stream) CK(ttsk_stream_wait(stream, q));                         // join
     }
 #undef CK
     return TTSK_OK;

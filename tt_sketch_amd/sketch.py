@@ -8,6 +8,8 @@ Omega-pseudoinverse assembly (:400-443) runs as device Jacobi-SVD + MFMA GEMM.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence, Tuple, Type
 
 import numpy as np
@@ -267,6 +269,39 @@ def nat_streams() -> int:
     return _native.NUM_STREAMS
 
 
+def _assemble_one_call(Psi, Om, direction):
+    """The d - 1 (pseudo-inverse, product) pairs through ``ttsk_tt_assemble``: one library call that deals them over the
+    library's streams and joins them, instead of 3 (d - 1) calls from here.  None if an operand is not a plain array."""
+    import ctypes
+    from . import _native as nat
+    d = len(Psi)
+    if d < 2 or len(Om) != d - 1 or not all(isinstance(a, DevArray) for a in list(Psi) + list(Om)):
+        return None
+    if os.environ.get("TTSK_ASSEMBLE_ONE_CALL", "1") == "0":
+        return None
+    if any(s != 0 and s in nat._dirty and nat._joined_into.get(s) != 0 for s in range(nat.NUM_STREAMS)):
+        sync()                                    # operands may still be in flight on another stream
+    Psi = [p.contiguous() for p in Psi]
+    Om = [o.contiguous() for o in Om]
+    lr, rr = [int(o.shape[0]) for o in Om], [int(o.shape[1]) for o in Om]
+    n = [int(p.shape[1]) for p in Psi]
+    for mu, p in enumerate(Psi):
+        want = (1 if mu == 0 else lr[mu - 1], n[mu], 1 if mu == d - 1 else rr[mu])
+        if tuple(p.shape) != want:
+            return None
+    if direction == "right":
+        cores = [DevArray.empty((1 if mu == 0 else lr[mu - 1], n[mu], lr[mu])) for mu in range(d - 1)] + [Psi[-1]]
+    else:
+        cores = [Psi[0]] + [DevArray.empty((rr[mu - 1], n[mu], 1 if mu == d - 1 else rr[mu])) for mu in range(1, d)]
+    work = [DevArray.empty((rr[k], lr[k])) for k in range(d - 1)]
+    I64, P = ctypes.c_int64, ctypes.c_void_p
+    nat.call("ttsk_tt_assemble", d, (I64 * d)(*n), (I64 * (d - 1))(*lr), (I64 * (d - 1))(*rr), (P * d)(*[p.ptr for p in Psi]),
+             (P * (d - 1))(*[o.ptr for o in Om]), (P * d)(*[c.ptr for c in cores]), (P * (d - 1))(*[w.ptr for w in work]),
+             0 if direction == "right" else 1, 0)
+    nat.call("ttsk_sync", 0)                      # operands and the pseudo-inverses are released after this
+    return cores
+
+
 def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool = False) -> ArrayList:
     """TT cores from a streaming sketch: C_mu = Psi_mu pinv(Omega_mu) ("right") or
     pinv(Omega_{mu-1}) Psi_mu ("left") (reference sketch.py:400-443)."""
@@ -276,6 +311,11 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool
     # device-resident: the d-1 (pinv, product) pairs are independent -> one library stream each, so
     # that the one-workgroup Jacobi kernels (~2 ms at rank 50 x 100) run side by side
     Psi, Om = sketch.device_arrays()
+    if direction not in ("right", "left"):
+        raise ValueError(f"Unknown direction {direction}")
+    one = _assemble_one_call(Psi, Om, direction)
+    if one is not None:
+        return one if device else [np.asarray(to_host(C)) for C in one]
     nstreams = max(1, min(len(Om), nat_streams()))
     sync()
     pending, keep = [], []          # `keep`: operands stay allocated until the streams have drained
