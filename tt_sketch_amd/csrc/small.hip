@@ -2,11 +2,15 @@
 // pure latency.  One wave per 16 x 32 output tile, operands straight from memory into MFMA
 // registers for the whole K (ring of 8 k-blocks in flight), no LDS and no barrier; up to
 // SK_MAXB problems of one shape (the tensors of a batch, or a uniformly strided batch) per launch.
-// Long contractions (K >= 256: Omega of a sum of 32 terms has K = 640) are cut over the 2 or 4 waves of a
-// workgroup, the partial tiles summed in wave order through LDS (round 3: 25 -> ~10 us per product at C5).
+// Long contractions (K >= 128: Omega of a sum of 32 terms has K = 640) are cut over 2, 4 or 8 waves of a
+// workgroup, the partial tiles summed in wave order through LDS.
 // tensor_train_sketch.py:8-19 (Omega), tensor_train_drm.py:79-88 (first mode) in the reference.
 #include <cstdlib>
 #include "skinny.h"
+
+#ifndef SMALL_DEPTH
+#define SMALL_DEPTH 16       // k-blocks in flight per wave (operands written by the previous kernel come from another XCD's L2: ~2 us a round trip)
+#endif
 
 namespace ttsk {
 
@@ -20,11 +24,11 @@ struct SmallG {
     int accumulate;
 };
 
-constexpr int SG_D = 8;
+constexpr int SG_D = SMALL_DEPTH;
 
-__global__ __launch_bounds__(256) void small_gemm_kernel(SmallG a)
+__global__ __launch_bounds__(512) void small_gemm_kernel(SmallG a)
 {
-    __shared__ double part[3][64][9];                 // partial tiles of waves 1..3 (padded rows)
+    __shared__ double part[7][64][9];                 // partial tiles of waves 1..7 (padded rows)
     const int lane = threadIdx.x & 63, x16 = lane & 15, kq = lane >> 4;
     const int ws = threadIdx.x >> 6, nws = blockDim.x >> 6;
     int w = blockIdx.x;
@@ -164,7 +168,9 @@ int small_try_batch(const ttsk_gemm_desc &d, int nb, const double *const *A, con
     g.accumulate = d.accumulate;
     const bool prof = prof_on();
     if (prof) prof_open(st, 2.0 * count * (double)d.M * (double)d.N * (double)K, 5, 0, false, false);
-    const int ksplit = K >= 512 ? 4 : (K >= 256 ? 2 : 1);
+    static const int ks_max = [] { const char *e = getenv("TTSK_SMALL_KSPLIT"); return e ? atoi(e) : 8; }();
+    int ksplit = K >= 512 ? 8 : (K >= 256 ? 4 : (K >= 128 ? 2 : 1));
+    if (ksplit > ks_max) ksplit = ks_max;
     hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)(count * g.tiles_m * g.tiles_n)), dim3(64 * ksplit), 0, st, g);
     if (prof) prof_close(st);
     TTSK_LAUNCH_CHECK();
