@@ -58,9 +58,11 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
                     if (k < 4 * K4) As[r * SA + k] = k < p.K ? v[r][h] : 0.0;
                 }
         } else {
+#pragma nounroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = (int64_t)t * 16 + r;
                 const double *ar = p.A + (row < p.m ? row : p.m - 1) * p.lda;
+#pragma nounroll
                 for (int k = lane; k < 4 * K4; k += 64) As[r * SA + k] = k < p.K ? ar[k] : 0.0;
             }
         }
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512) void tall_mul_kernel(TallMul p)   // launched 
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
         const double *ap = As + x16 * SA + g, *bp = sm + g * SB + x16;
-#pragma unroll 4
+
         for (int kb = 0; kb < K4; ++kb) {
             const double a = ap[4 * kb];
 #pragma unroll
