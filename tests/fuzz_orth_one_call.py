@@ -1,0 +1,89 @@
+"""Randomised sweep of the one-call orthogonal / hmt sketch and of the one-call assembly against the oracle
+(a tool, not collected by pytest):  python tests/fuzz_orth_one_call.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ttsk_oracle as orc  # noqa: E402
+import tt_sketch_amd as tsa  # noqa: E402
+from tt_sketch_amd import _native, tt_fused  # noqa: E402
+from tt_sketch_amd.sketch import assemble_sketched_tt  # noqa: E402
+
+_native.call("ttsk_init", 0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+hits = {"one": 0, "other": 0}
+real = tt_fused.try_orth_sketch
+
+
+def spy(*a, **k):
+    out = real(*a, **k)
+    hits["one" if out is not None else "other"] += 1
+    return out
+
+
+tt_fused.try_orth_sketch = spy
+
+
+def close(got, want, tol, what):
+    assert [np.asarray(c).shape for c in got] == [np.asarray(c).shape for c in want], what
+    for k, (g, w) in enumerate(zip(got, want)):
+        g, w = np.asarray(g), np.asarray(w)
+        err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-300)
+        assert err <= tol, (what, k, err)
+
+
+t0, cases = time.time(), 0
+while time.time() - t0 < budget:
+    d = int(rng.integers(2, 7))
+    shape = tuple(int(x) for x in rng.integers(2, 40, size=d))
+    s_in = tuple(int(x) for x in rng.integers(1, 25, size=d - 1))
+    equal = rng.random() < 0.5
+    if equal:
+        l = (int(rng.integers(1, 20)),) * (d - 1)
+        r = (l[0] + int(rng.integers(1, 20)),) * (d - 1)
+    else:
+        l = tuple(int(x) for x in rng.integers(1, 20, size=d - 1))
+        r = tuple(x + int(y) for x, y in zip(l, rng.integers(1, 20, size=d - 1)))
+    # the reference trims sketch ranks to what the unfoldings allow
+    l = tuple(tsa.utils.process_tt_rank(l, shape, trim=True))
+    r = tuple(tsa.utils.process_tt_rank(r, shape, trim=True))
+    if not all(a < b for a, b in zip(l, r)):
+        continue
+    # cores are compared entry by entry: the unfoldings have to have full column rank (TT rank >= sketch rank), else the
+    # completion of Q is arbitrary
+    s_in = tuple(max(a, b) for a, b in zip(s_in, l))
+    cores = orc.random_tt(shape, s_in, rng)
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left = tsa.TensorTrainDRM(l, shape, False, seed=1, cores=[np.array(c) for c in ld.cores])
+    right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=[np.array(c) for c in rd.cores])
+    X = tsa.TensorTrain(cores)
+    what = f"shape {shape} s {s_in} l {l} r {r}"
+    try:
+        want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+        got = tsa.orthogonal_sketch(X, l, r, left_drm=left, right_drm=right).cores
+        close(got, want, 1e-7, "orthogonal " + what)
+        rdh = orc.random_tt_drm(shape, l, True, rng)
+        righth = tsa.TensorTrainDRM(l, shape, True, seed=3, cores=[np.array(c) for c in rdh.cores])
+        want, _ = orc.general_sketch("tt", cores, None, rdh, "hmt")
+        got = tsa.hmt_sketch(X, l, drm=righth).cores
+        close(got, want, 1e-7, "hmt " + what)
+        stt = tsa.stream_sketch(X, l, r, left_drm=left, right_drm=right)
+        P, O = orc.general_sketch("tt", cores, ld, rd, "streaming")
+        for direction in ("right", "left"):
+            one = assemble_sketched_tt(stt.sketch_, direction=direction)
+            ref = orc.assemble(P, O, direction=direction) if "direction" in orc.assemble.__code__.co_varnames else None
+            os.environ["TTSK_ASSEMBLE_ONE_CALL"] = "0"
+            pairs = assemble_sketched_tt(stt.sketch_, direction=direction)
+            os.environ["TTSK_ASSEMBLE_ONE_CALL"] = "1"
+            close(one, pairs, 1e-8, f"assemble {direction} " + what)
+            if ref is not None:
+                close(one, ref, 1e-6, f"assemble-vs-oracle {direction} " + what)
+    except AssertionError:
+        print("FAILED", what, flush=True)
+        raise
+    cases += 1
+print(f"{cases} cases green ({hits['one']} sketches through the one-call path, {hits['other']} declined) in {time.time() - t0:.0f} s")
