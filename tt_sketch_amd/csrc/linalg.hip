@@ -474,6 +474,113 @@ __device__ void hh_signs_lds(double *B, int n, int ld, int square, double *S, do
 // and writes Rinv with its columns scaled by them: three launches of qr_cholesky in one.
 // sticky (optional): set to 1 on rejection, never cleared here (deferred verdicts: ttsk_orth_step);
 // pminmax (optional): smallest / largest pivot, for callers that combine several blocks (chol_inv_any).
+// The factorisation and the inverse of chol_inv_kernel on a matrix that sits in LDS (A: n x n with row stride ld, both
+// triangles; xd: n doubles): afterwards X = R^-1 is stored with its strict upper part transposed into A's lower
+// triangle (X[i][c], i < c, at A[c][i]) and its diagonal in xd.  Every thread of the workgroup calls it (barriers
+// inside); threads beyond the first 256 take part in the recurrence only.  bad / pmin / pmax: the verdict's inputs
+// (every thread has them).
+__device__ __forceinline__ void chol_lds(double *A, double *xd, const int n, const int ld, double *shadow, const int tid,
+                                         const int nthr, int &bad, double &pmin, double &pmax)
+{
+    const bool core = tid < 256;
+    const int ti = tid >> 4, tc = tid & 15, nrow = nthr >> 4;
+    auto rcp2 = [](double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); };
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+        const double *r0 = A + j * ld, *r1 = A + (j + 1) * ld;
+        double p0 = r0[j];
+        if (!(p0 > 0.0)) { bad = 1; p0 = 1.0; }
+        const double pi0 = rcp2(p0);
+        const double g = r0[j + 1] * pi0;                      // factor of row j + 1 against row j
+        double p1 = fma(-g, r0[j + 1], r1[j + 1]);             // pivot of column j + 1 after step j
+        if (!(p1 > 0.0)) { bad = 1; p1 = 1.0; }
+        const double pi1 = rcp2(p1);
+        pmin = fmin(pmin, fmin(p0, p1));
+        pmax = fmax(pmax, fmax(p0, p1));
+        for (int i = j + 2 + ti; i < n; i += nrow) {
+            const double a0 = r0[i], a1 = fma(-g, a0, r1[i]);  // A[j][i] and A[j+1][i] after step j
+            const double f0 = a0 * pi0, f1 = a1 * pi1;
+            for (int c = i + tc; c < n; c += 16) {
+                const double u1 = fma(-g, r0[c], r1[c]);       // row j + 1 after step j, at c
+                A[i * ld + c] = fma(-f1, u1, fma(-f0, r0[c], A[i * ld + c]));
+            }
+        }
+        double *sh = shadow + ((j >> 1) & 1) * 128;
+        for (int c = j + 1 + tid; c < n; c += nthr) sh[c] = fma(-g, r0[c], r1[c]);
+        __syncthreads();
+        for (int c = j + 1 + tid; c < n; c += nthr) A[(j + 1) * ld + c] = sh[c];
+    }
+    __syncthreads();
+    if (j < n) {                                               // odd n: the last pivot
+        double piv = A[j * ld + j];
+        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+        pmin = fmin(pmin, piv);
+        pmax = fmax(pmax, piv);
+    }
+    // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
+    if (core && tid < n) xd[tid] = 1.0 / sqrt(A[tid * ld + tid] > 0.0 ? A[tid * ld + tid] : 1.0);
+    __syncthreads();
+    if (core)
+        for (int jj = ti; jj < n; jj += 16) {
+            const double sc = xd[jj];
+            for (int c = jj + tc; c < n; c += 16) A[jj * ld + c] *= sc;
+        }
+    __syncthreads();
+    // X = R^-1 stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused strict lower triangle of A at
+    // A[c][i], its diagonal to xd[].
+    // X = R^-1 in 16 x 16 blocks.  (1) The diagonal blocks, all at once: a quad of lanes owns a column and walks the
+    // (up to 15) rows of its own block -- one wavefront per 16 columns, in order, no workgroup barrier.  (2) Block rows
+    // from the bottom: X_ij = -X_ii (sum_{i<k<=j} R_ik X_kj) on the matrix cores; the accumulator registers of the sum
+    // are the B operand of the second product (register kb of a lane holds rows 4 kb + (lane >> 4): exactly k-block
+    // kb); one barrier per block row.  (One column per quad over ALL rows was 42 k of the kernel's 118 k cycles at
+    // n = 50 -- 900 cycles of dependent LDS reads per row -- and 152 k of 396 k at n = 100; now 20 k and 55 k.)
+    const int q4 = tid & 3, col4 = tid >> 2;
+    for (int c = core ? col4 : n; c < n; c += 64) {
+        const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
+        const int top = c & ~15;
+        for (int i = c - 1; i >= top; --i) {
+            const double *ri = A + i * ld;
+            double acc = 0.0;
+            for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
+            acc += jac_dpp<0xB1>(acc);              // quad_perm 1 0 3 2
+            acc += jac_dpp<0x4E>(acc);              // quad_perm 2 3 0 1
+            if (q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
+        }
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6, x16 = lane & 15, kq = lane >> 4;
+        const int nt = (n + 15) >> 4;
+        // X(r, c), r <= c, from its storage: strict upper part transposed into the lower triangle, diagonal in xd
+        auto Xat = [&](int r, int c) -> double {
+            if (r >= n || c >= n || r > c) return 0.0;
+            return r == c ? xd[c] : A[c * ld + r];
+        };
+        for (int bi = nt - 2; bi >= 0; --bi) {
+            for (int bj = core ? bi + 1 + wv : nt; bj < nt; bj += 4) {
+                v4d S = {0.0, 0.0, 0.0, 0.0};
+                const int ra = 16 * bi + x16;
+                for (int bk = bi + 1; bk <= bj; ++bk)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const int k = 16 * bk + 4 * kb + kq;
+                        const double av = (ra < n && k < n) ? A[ra * ld + k] : 0.0;          // R[ra][k], k > ra
+                        S = mfma16(av, Xat(k, 16 * bj + x16), S);
+                    }
+                v4d Xn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) Xn = mfma16(Xat(16 * bi + x16, 16 * bi + 4 * kb + kq), S[kb], Xn);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = 16 * bi + kq + 4 * jj, c = 16 * bj + x16;
+                    if (r < n && c < n) A[c * ld + r] = -Xn[jj];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Launched with 256 threads, or with 1024 (n <= 64, chol_threads()): the extra twelve waves take part in the recurrence
 // only -- one row per 16-lane group instead of four, twelve more waves to hide the LDS round trips behind -- and leave.
 __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ G, int n, double *__restrict__ Rinv,
@@ -540,104 +647,13 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
     }
     if (expanded && !core) return;
     if (!expanded) {
-    for (; j + 1 < n; j += 2) {
-        const double *r0 = A + j * ld, *r1 = A + (j + 1) * ld;
-        double p0 = r0[j];
-        if (!(p0 > 0.0)) { bad = 1; p0 = 1.0; }
-        const double pi0 = rcp2(p0);
-        const double g = r0[j + 1] * pi0;                      // factor of row j + 1 against row j
-        double p1 = fma(-g, r0[j + 1], r1[j + 1]);             // pivot of column j + 1 after step j
-        if (!(p1 > 0.0)) { bad = 1; p1 = 1.0; }
-        const double pi1 = rcp2(p1);
-        pmin = fmin(pmin, fmin(p0, p1));
-        pmax = fmax(pmax, fmax(p0, p1));
-        for (int i = j + 2 + ti; i < n; i += nrow) {
-            const double a0 = r0[i], a1 = fma(-g, a0, r1[i]);  // A[j][i] and A[j+1][i] after step j
-            const double f0 = a0 * pi0, f1 = a1 * pi1;
-            for (int c = i + tc; c < n; c += 16) {
-                const double u1 = fma(-g, r0[c], r1[c]);       // row j + 1 after step j, at c
-                A[i * ld + c] = fma(-f1, u1, fma(-f0, r0[c], A[i * ld + c]));
-            }
-        }
-        double *sh = shadow + ((j >> 1) & 1) * 128;
-        for (int c = j + 1 + tid; c < n; c += nthr) sh[c] = fma(-g, r0[c], r1[c]);
-        __syncthreads();
-        for (int c = j + 1 + tid; c < n; c += nthr) A[(j + 1) * ld + c] = sh[c];
-    }
-    __syncthreads();
+    chol_lds(A, xd, n, ld, shadow, tid, nthr, bad, pmin, pmax);
     if (!core) return;
-    if (j < n) {                                               // odd n: the last pivot
-        double piv = A[j * ld + j];
-        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-        pmin = fmin(pmin, piv);
-        pmax = fmax(pmax, piv);
-    }
     if (tid == 0) {
         const int rej = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
         status[0] = rej;
         if (rej && sticky) *sticky = 1;
         if (pminmax) { pminmax[0] = bad ? -1.0 : pmin; pminmax[1] = pmax; }
-    }
-    // R[j][c] = row j / r_j; xd[j] = 1 / R[j][j] = 1 / r_j
-    if (tid < n) xd[tid] = 1.0 / sqrt(A[tid * ld + tid] > 0.0 ? A[tid * ld + tid] : 1.0);
-    __syncthreads();
-    for (int jj = ti; jj < n; jj += 16) {
-        const double sc = xd[jj];
-        for (int c = jj + tc; c < n; c += 16) A[jj * ld + c] *= sc;
-    }
-    __syncthreads();
-    // X = R^-1 stays in LDS: its strict upper part X[i][c] (i < c) goes to the unused strict lower triangle of A at
-    // A[c][i], its diagonal to xd[].
-    // X = R^-1 in 16 x 16 blocks.  (1) The diagonal blocks, all at once: a quad of lanes owns a column and walks the
-    // (up to 15) rows of its own block -- one wavefront per 16 columns, in order, no workgroup barrier.  (2) Block rows
-    // from the bottom: X_ij = -X_ii (sum_{i<k<=j} R_ik X_kj) on the matrix cores; the accumulator registers of the sum
-    // are the B operand of the second product (register kb of a lane holds rows 4 kb + (lane >> 4): exactly k-block
-    // kb); one barrier per block row.  (One column per quad over ALL rows was 42 k of the kernel's 118 k cycles at
-    // n = 50 -- 900 cycles of dependent LDS reads per row -- and 152 k of 396 k at n = 100; now 20 k and 55 k.)
-    const int q4 = tid & 3, col4 = tid >> 2;
-    for (int c = col4; c < n; c += 64) {
-        const double *xc = A + c * ld;                                  // X[k][c] at A[c][k], k < c
-        const int top = c & ~15;
-        for (int i = c - 1; i >= top; --i) {
-            const double *ri = A + i * ld;
-            double acc = 0.0;
-            for (int k = i + 1 + q4; k < c; k += 4) acc = fma(ri[k], xc[k], acc);
-            acc += jac_dpp<0xB1>(acc);              // quad_perm 1 0 3 2
-            acc += jac_dpp<0x4E>(acc);              // quad_perm 2 3 0 1
-            if (q4 == 0) A[c * ld + i] = -(acc + ri[c] * xd[c]) * xd[i];
-        }
-    }
-    __syncthreads();
-    {
-        const int lane = tid & 63, wv = tid >> 6, x16 = lane & 15, kq = lane >> 4;
-        const int nt = (n + 15) >> 4;
-        // X(r, c), r <= c, from its storage: strict upper part transposed into the lower triangle, diagonal in xd
-        auto Xat = [&](int r, int c) -> double {
-            if (r >= n || c >= n || r > c) return 0.0;
-            return r == c ? xd[c] : A[c * ld + r];
-        };
-        for (int bi = nt - 2; bi >= 0; --bi) {
-            for (int bj = bi + 1 + wv; bj < nt; bj += 4) {
-                v4d S = {0.0, 0.0, 0.0, 0.0};
-                const int ra = 16 * bi + x16;
-                for (int bk = bi + 1; bk <= bj; ++bk)
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {
-                        const int k = 16 * bk + 4 * kb + kq;
-                        const double av = (ra < n && k < n) ? A[ra * ld + k] : 0.0;          // R[ra][k], k > ra
-                        S = mfma16(av, Xat(k, 16 * bj + x16), S);
-                    }
-                v4d Xn = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) Xn = mfma16(Xat(16 * bi + x16, 16 * bi + 4 * kb + kq), S[kb], Xn);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int r = 16 * bi + kq + 4 * jj, c = 16 * bj + x16;
-                    if (r < n && c < n) A[c * ld + r] = -Xn[jj];
-                }
-            }
-            __syncthreads();
-        }
     }
     }   // !expanded
     // X(r, c) from that storage (zero below the diagonal): the results are written straight from it -- no pass that
