@@ -1054,6 +1054,8 @@ size_t qr_ws_elems(int64_t m, int n) { return (size_t)m * n + 4 * (size_t)n * n 
 
 // thin QR by CholeskyQR2 + Householder sign reconstruction; 1 = done, 0 = rejected.  sticky: deferred mode -- the
 // factorisation always runs to the end (A is overwritten either way), a rejection is recorded in *sticky.
+static int launch_cholqr2_lds(double *M, int64_t m, int n, int *status, double cond_tol, int *sticky, hipStream_t st);
+
 int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, double *ws_in, int *sticky, bool unsigned_q)
 {
     const int n = (int)n64;
@@ -1073,6 +1075,12 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
     if (!ws) return TTSK_ERR_HIP;
     double *Q1 = ws, *G = Q1 + (size_t)m * n, *R1 = G + n * n, *R2 = R1 + n * n, *Qtop = R2 + n * n;
     int *status = (int *)(Qtop + n * n);
+    static const int small_on = [] { const char *e = getenv("TTSK_CHOLQR2_LDS"); return e ? atoi(e) : 1; }();
+    if (unsigned_q && sticky && small_on) {
+        // small enough for one workgroup's LDS: the whole CholeskyQR2 in one launch
+        const int fr = launch_cholqr2_lds(A, m, n, status, 1e-6, sticky, st);
+        if (fr) return fr;
+    }
     double *cws = n > CHOL_ONE ? Qtop + n * n + 16 : nullptr;
     int rc;
     if ((rc = small_gemm(n, n, m, A, 1, n, A, n, 1, G, stream))) return rc;              // A^T A
@@ -1117,6 +1125,180 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
         if (host_status[0] || host_status[1]) return 0;
     }
     if ((rc = small_gemm(m, n, n, Q1, n, 1, R2, n, 1, A, stream))) return rc;            // Q = Q1 R2^-1 S
+    return 1;
+}
+
+// CholeskyQR2 of a SMALL tall matrix in ONE workgroup (m (n + 2) + n (n + 1) + n doubles fit the LDS: the first mode of an
+// orthogonalising sketch, 200 x 50 at C3): M (m x n, row-major, in place) -> Q with the signs of CholeskyQR (R's diagonal
+// positive; the caller reconstructs Householder's signs with qr_signs).  Both Gram matrices, both factorisations, both
+// products without leaving the LDS: one launch instead of eight (Gram + reduce, factorisation, product, twice).
+// status[0] / status[1]: verdicts of the two factorisations as chol_inv_kernel gives them (gates cond_tol, 0.5).
+constexpr size_t CHOLQR2_LDS_MAX = 19000;       // doubles
+__global__ __launch_bounds__(1024) void cholqr2_lds_kernel(double *__restrict__ M, int m, int n, int *__restrict__ status,
+                                                           double cond_tol, int *__restrict__ sticky)
+{
+    extern __shared__ double sm[];
+    __shared__ double shadow[2 * 128];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6, x16 = lane & 15, g = lane >> 4;
+    // operands zero-padded to whole tiles, so that the matrix-core loops carry no bounds
+    const int nt = (n + 15) >> 4, mt = (m + 15) >> 4, np = 16 * nt, mp = 16 * mt, ldm = np + 2, ld = np + 1;
+    double *Ms = sm, *A = sm + (size_t)mp * ldm, *xd = A + (size_t)np * ld;
+    const bool core = tid < 256;
+    for (int e = tid; e < mp * ldm; e += nthr) Ms[e] = 0.0;
+    for (int e = tid; e < np * ld + np; e += nthr) A[e] = 0.0;
+    __syncthreads();
+    for (int e0 = tid; e0 < m * n; e0 += 8 * nthr) {          // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = e0 + u * nthr < m * n ? M[e0 + u * nthr] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * nthr;
+            if (e < m * n) Ms[(e / n) * ldm + e % n] = v[u];
+        }
+    }
+    __syncthreads();
+    // A = Ms^T Ms: one tile pair (t1 <= t2) per wave and turn, the whole column of row blocks
+    auto gram = [&]() {
+        int q = 0;
+        for (int t1 = 0; t1 < nt; ++t1)
+            for (int t2 = t1; t2 < nt; ++t2, ++q) {
+                if (q % nw != wv) continue;
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                const double *pa = Ms + g * ldm + 16 * t1 + x16, *pb = Ms + g * ldm + 16 * t2 + x16;
+                // four k-blocks per step (a row tile of Ms), the next step's operands read before this step's matrix instructions
+                double a[4], b[4], an[4], bn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = pa[4 * u * ldm]; b[u] = pb[4 * u * ldm]; }
+                for (int s4 = 0; s4 < mt; ++s4) {
+                    const int nx = s4 + 1 < mt ? s4 + 1 : s4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { an[u] = pa[(16 * nx + 4 * u) * ldm]; bn[u] = pb[(16 * nx + 4 * u) * ldm]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = mfma16(a[u], b[u], acc);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * t1 + g + 4 * v, c = 16 * t2 + x16;
+                    if (r < n && c < n) { A[r * ld + c] = acc[v]; A[c * ld + r] = acc[v]; }
+                }
+            }
+    };
+    // X from chol_lds's storage (strict upper part transposed into the lower triangle, diagonal in xd) to a dense upper
+    // triangular matrix in A, in place
+    auto densify = [&]() {
+        for (int e = tid; e < n * n; e += nthr) {
+            const int i = e / n, c = e - i * n;
+            if (i < c) { const double t = A[c * ld + i]; A[i * ld + c] = t; A[c * ld + i] = 0.0; }
+            else if (i == c) A[i * ld + i] = xd[i];
+        }
+    };
+    // rows of Ms (or of the output) <- rows of Ms times A; a wave owns its row tiles
+    auto apply = [&](double *out, int ldo) {
+        for (int tile = wv; tile < mt; tile += nw) {
+            v4d acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+            const double *pa = Ms + (16 * tile + x16) * ldm + g, *pb = A + g * ld + x16;
+            // the operands of k-block kb + 1 are read before the matrix instructions of k-block kb
+            double a = pa[0], b[4], an, bn[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = t < nt ? pb[16 * t] : 0.0;
+            for (int kb = 0; kb < 4 * nt; ++kb) {
+                const int nx = kb + 1 < 4 * nt ? kb + 1 : kb;
+                an = pa[4 * nx];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bn[t] = t < nt ? pb[4 * nx * ld + 16 * t] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < nt) acc[t] = mfma16(a, b[t], acc[t]);
+                a = an;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = bn[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * tile + g + 4 * v, c = 16 * t + x16;
+                    if (t < nt && r < m && c < n) out[(size_t)r * ldo + c] = acc[t][v];
+                }
+        }
+    };
+    gram();
+    __syncthreads();
+    int bad = 0;
+    double pmin = 1e300, pmax = 0.0;
+    chol_lds(A, xd, n, ld, shadow, tid, nthr, bad, pmin, pmax);
+    if (tid == 0) {
+        const int rej = (bad || pmin < cond_tol * cond_tol * pmax) ? 1 : 0;
+        status[0] = rej;
+        if (rej && sticky) *sticky = 1;
+    }
+    densify();
+    __syncthreads();
+    apply(Ms, ldm);                                        // Q1 = M R1^-1 in place
+    __syncthreads();
+    gram();                                                // overwrites A's n x n block (both triangles)
+    __syncthreads();
+    // second factor: I - Phi(E) where the Gram matrix is the identity to 1e-8 / n, the recurrence otherwise
+    double em = 0.0;
+    if (core) {
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, c = e - i * n;
+            em = fmax(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
+        }
+        em = fmax(em, jac_dpp<0xB1>(em));
+        em = fmax(em, jac_dpp<0x4E>(em));
+        if ((tid & 3) == 0) shadow[tid >> 2] = em;
+    }
+    __syncthreads();
+    em = 0.0;
+    for (int k = 0; k < 64; ++k) em = fmax(em, shadow[k]);
+    __syncthreads();
+    if (em * n <= 1e-8) {
+        for (int e = tid; e < n * n; e += nthr) {           // dense X2 = I - Phi(E) in place
+            const int i = e / n, c = e - i * n;
+            if (i < c) A[i * ld + c] = -A[i * ld + c];
+            else if (i == c) A[i * ld + i] = 1.0 - 0.5 * (A[i * ld + i] - 1.0);
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nthr) {
+            const int i = e / n, c = e - i * n;
+            if (i > c) A[i * ld + c] = 0.0;
+        }
+        if (tid == 0) status[1] = 0;
+    } else {
+        bad = 0; pmin = 1e300; pmax = 0.0;
+        chol_lds(A, xd, n, ld, shadow, tid, nthr, bad, pmin, pmax);
+        if (tid == 0) {
+            const int rej = (bad || pmin < 0.25 * pmax) ? 1 : 0;
+            status[1] = rej;
+            if (rej && sticky) *sticky = 1;
+        }
+        densify();
+    }
+    __syncthreads();
+    apply(M, n);                                           // Q = Q1 R2^-1
+}
+
+// 1 = queued, 0 = does not fit
+static int launch_cholqr2_lds(double *M, int64_t m, int n, int *status, double cond_tol, int *sticky, hipStream_t st)
+{
+    if (n > 64 || m < n || m > 4096) return 0;
+    const size_t np = 16 * (size_t)((n + 15) >> 4), mp = 16 * (size_t)((m + 15) >> 4);
+    const size_t elems = mp * (np + 2) + np * (np + 1) + np;
+    if (elems > CHOLQR2_LDS_MAX) return 0;
+    static bool attr = false;
+    if (!attr) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)cholqr2_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        attr = true;
+    }
+    const size_t lds = elems * 8;
+    hipLaunchKernelGGL(cholqr2_lds_kernel, dim3(1), dim3(1024), lds, st, M, (int)m, n, status, cond_tol, sticky);
+    TTSK_LAUNCH_CHECK();
     return 1;
 }
 
