@@ -145,6 +145,24 @@ def try_stream_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[lis
     return plan0.views(out)
 
 
+def _carve(shapes) -> List[DevArray]:
+    """contiguous arrays of the given shapes as views of one allocation (16-byte aligned pieces)"""
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += n + (n & 1)
+    buf = DevArray.empty((max(tot, 1),))
+    out = []
+    for sh, off in zip(shapes, offs):
+        st, acc = [], 1
+        for n in reversed(sh):
+            st.append(acc)
+            acc *= int(n)
+        out.append(DevArray(buf.buf, off, sh, tuple(reversed(st))))
+    return out
+
+
 def try_orth_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list, list]]:
     """``orthogonal`` / ``hmt`` sketch of ONE tensor train with tensor-train DRMs through ``ttsk_tt_orth_sketch``:
     (cores, Omega) as device arrays, or None if the one-call path does not apply.  The verdicts of its fast
@@ -176,13 +194,15 @@ def try_orth_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list,
         keep.append([c.contiguous() for c in left_drm.dev_cores()])
         DL = (P * (d - 1))(*[c.ptr for c in keep[2]])
         out_rank = tuple(left_drm.rank)
-        Omega = [DevArray.empty((out_rank[mu], right_rank[mu])) for mu in range(d - 1)]
-        om = (P * (d - 1))(*[o.ptr for o in Omega])
+        om_shapes = [(out_rank[mu], right_rank[mu]) for mu in range(d - 1)]
     else:
-        lt, DL, om, Omega = None, None, None, []
+        lt, DL, om_shapes = None, None, []
         out_rank = right_rank
     kr = (1,) + out_rank + (1,)
-    cores = [DevArray.empty((kr[mu], tensor.shape[mu], kr[mu + 1])) for mu in range(d)]
+    # every output of the call in ONE allocation (a dozen pool round trips cost the host more than the device idles for)
+    arrs = _carve([(kr[mu], tensor.shape[mu], kr[mu + 1]) for mu in range(d)] + om_shapes)
+    cores, Omega = arrs[:d], arrs[d:]
+    om = (P * (d - 1))(*[o.ptr for o in Omega]) if orth else None
     try:
         nat.call("ttsk_tt_orth_sketch", d, n, s, lt, rt, X, DL, DR, (P * d)(*[c.ptr for c in cores]), om, 0)
     except nat.TtskUnsupported:
