@@ -338,12 +338,6 @@ int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64
 int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *rr, const double *const *dev_psi,
                      const double *const *dev_omega, double *const *dev_cores_out, double *const *dev_work, int direction,
                      int stream);
-/* Y (m, n) = A (m, K) B (K, n), all contiguous row-major, and -- G != NULL -- G (n, n) = Y^T Y from the same launch
- * (the tile of Y is both MFMA operands of its own Gram product): the "product, then Gram matrix" pairs of CholeskyQR2
- * inside ttsk_tt_orth_sketch (sketch_dispatch.py:160-174).  n <= 64, K n within the LDS; else TTSK_ERR_UNSUPPORTED. */
-int ttsk_tall_mul(const double *dev_A, int64_t m, int64_t K, const double *dev_B, int64_t n, double *dev_Y, double *dev_G,
-                  int stream);
-
 /* ---- multi-GPU: one RCCL sum of the packed partial sketch ------------------
  * SketchContainer.__add__ across ranks (sketch_container.py:61-69). */
 int ttsk_comm_unique_id(void *host_id128);                 /* rank 0: 128-byte id */

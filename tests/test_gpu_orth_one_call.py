@@ -160,53 +160,6 @@ def test_one_call_rejection_repeats_on_the_robust_path(tsa, monkeypatch):
     assert out.error(X) < 1e-10
 
 
-@pytest.mark.parametrize("m,K,n", [(10000, 100, 50), (37, 5, 3), (1000, 33, 64), (16, 4, 16), (4099, 130, 17), (200, 100, 50)])
-def test_tall_mul_with_gram(tsa, m, K, n):
-    """Y = A B and G = Y^T Y from one launch (tall_qr.hip) against numpy"""
-    from tt_sketch_amd import _native as nat
-    from tt_sketch_amd.device import DevArray, as_dev
-    rng = np.random.default_rng(m + K + n)
-    A, B = rng.standard_normal((m, K)), rng.standard_normal((K, n))
-    dA, dB = as_dev(A), as_dev(B)
-    Y, G = DevArray.empty((m, n)), DevArray.empty((n, n))
-    P = ctypes.c_void_p
-    nat.call("ttsk_tall_mul", P(dA.ptr), m, K, P(dB.ptr), n, P(Y.ptr), P(G.ptr), 0)
-    want = A @ B
-    assert np.abs(Y.get() - want).max() <= 1e-13 * np.abs(want).max()
-    gw = want.T @ want
-    assert np.abs(G.get() - gw).max() <= 1e-13 * np.abs(gw).max()
-    Y2 = DevArray.empty((m, n))
-    nat.call("ttsk_tall_mul", P(dA.ptr), m, K, P(dB.ptr), n, P(Y2.ptr), None, 0)
-    assert np.array_equal(Y2.get(), Y.get())
-
-
-def test_one_call_with_the_fused_tall_kernels(tsa, monkeypatch):
-    """TTSK_ORTH_TALL=1 (product and Gram matrix of CholeskyQR2 in one launch): read once per process, so this runs
-    in a child interpreter; same cores as the default path to rounding."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import numpy as np, tt_sketch_amd as tsa
-from tt_sketch_amd import _native
-_native.call("ttsk_init", 0)
-rng = np.random.default_rng(0)
-shape, s, l, r = (60, 60, 60, 60), 30, 20, 40
-ranks = (1,) + (s,) * 3 + (1,)
-cores = [rng.standard_normal((ranks[i], shape[i], ranks[i + 1])) for i in range(4)]
-tt = tsa.orthogonal_sketch(tsa.TensorTrain(cores), (l,) * 3, (r,) * 3, seed=3)
-np.save(__import__("sys").argv[1], np.concatenate([np.asarray(c).ravel() for c in tt.cores]))
-"""
-    outs = []
-    for flag in ("0", "1"):
-        path = f"/tmp/ttsk_tall_{os.getpid()}_{flag}.npy"
-        env = dict(os.environ, TTSK_ORTH_TALL=flag)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)), timeout=300)
-        outs.append(np.load(path))
-        os.remove(path)
-    assert np.abs(outs[0] - outs[1]).max() <= 1e-10 * np.abs(outs[0]).max()
-
-
 def test_pinv_batch_mixes_accepted_and_rejected_matrices(tsa):
     """ttsk_pinv_batch: five 12 x 30 matrices in one set of launches, two of them rank deficient (the Jacobi kernel takes
     over for exactly those, through its predicate) -- numpy.linalg.pinv's result for each (utils.py:98-109)."""

@@ -1398,36 +1398,6 @@ int apply_signs(int count, double *const *cores, const double *const *sp, const 
     return TTSK_OK;
 }
 
-size_t qr_mul_ws_elems(int64_t m, int n) { return (size_t)m * n + 3 * (size_t)n * n + 16 + tall_mul_ws_elems(m, n); }
-
-int qr_cholesky_mul(const double *A, int64_t lda, int K, const double *W, double *Q, int64_t m, int n, int stream, hipStream_t st,
-                    double *ws, int *sticky, bool unsigned_q)
-{
-    if (!sticky || !ws || n > 64 || n > CHOL_SIGN_MAX || m < 2 * (int64_t)n) return 0;
-    double *Q1 = ws, *G = Q1 + (size_t)m * n, *R1 = G + n * n, *R2 = R1 + n * n;
-    int *status = (int *)(R2 + n * n);
-    double *slab = R2 + n * n + 16;
-    int rc = tall_mul(A, lda, K, W, n, Q, n, m, n, G, slab, st);                          // M = A W, G = M^T M
-    if (rc <= 0) return rc;
-    if ((rc = launch_chol(G, n, R1, nullptr, status, 1e-6, st, sticky))) return rc;      // kappa(M) up to ~1e6
-    if ((rc = tall_mul(Q, n, n, R1, n, Q1, n, m, n, G, slab, st)) <= 0) return rc ? rc : TTSK_ERR_UNSUPPORTED;   // Q1 = M R1^-1, G = Q1^T Q1
-    static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
-    static bool attr = false;
-    if (!attr) {
-        TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr = true;
-    }
-    if (unsigned_q)
-        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, G, n, R2, (double *)nullptr,
-                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)nullptr, 0, chol_expand ? 2 : 0);
-    else
-        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(3 * n * (n + 1) + 2 * n) * 8, st, G, n, R2, (double *)nullptr,
-                           status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, 0, chol_expand);
-    TTSK_LAUNCH_CHECK();
-    if ((rc = tall_mul(Q1, n, n, R2, n, Q, n, m, n, nullptr, nullptr, st)) <= 0) return rc ? rc : TTSK_ERR_UNSUPPORTED;   // Q = Q1 R2^-1 S
-    return 1;
-}
-
 }  // namespace ttsk
 
 using namespace ttsk;

@@ -25,16 +25,4 @@ int pinv_deferred(const double *omega, int64_t l, int64_t r, double *pinv, int s
 int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
                 const int *k1, hipStream_t st);
 constexpr int QR_CHOL_MAX_N = 256;       // largest column count of qr_cholesky
-// Q (m x n) = Householder-signed Q of qr_thin(A W), A (m x K, row stride lda), W (K x n): the product and both Gram
-// matrices of CholeskyQR2 from the fused tall kernels (tall_qr.hip).  Deferred verdicts only (sticky != nullptr).
-// 1 = queued, 0 = outside these kernels (n > 64, K W beyond the LDS, nearly square) -- nothing was queued
-size_t qr_mul_ws_elems(int64_t m, int n);
-int qr_cholesky_mul(const double *A, int64_t lda, int K, const double *W, double *Q, int64_t m, int n, int stream, hipStream_t st,
-                    double *ws, int *sticky, bool unsigned_q = false);
-// tall_qr.hip: Y = A B and, G != nullptr, G = Y^T Y (slab: tall_mul_ws_elems doubles); 1 = queued, 0 = not covered
-size_t tall_mul_ws_elems(int64_t m, int n);
-int tall_mul(const double *A, int64_t lda, int K, const double *B, int64_t ldb, double *Y, int64_t ldy, int64_t m, int n,
-             double *G, double *slab, hipStream_t st);
-
-
 }  // namespace ttsk

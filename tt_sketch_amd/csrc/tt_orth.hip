@@ -91,8 +91,7 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     one_shape = one_shape && std::min(lt[1], rr(0)) <= 128;
     const size_t szP = orth ? blk(pmax) : 0, szW = orth ? blk((size_t)smax * lmax) : 0;
     const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax);
-    const size_t szQ = blk(std::max(qr_ws_elems(mmax, (int)kmax), qr_mul_ws_elems(mmax, (int)kmax)));
-    static const int tall_on = [] { const char *e = getenv("TTSK_ORTH_TALL"); return e ? atoi(e) : 0; }();   // (tall_qr.hip: not faster yet)
+    const size_t szQ = blk(qr_ws_elems(mmax, (int)kmax));
     const size_t szS = blk((size_t)kmax), szSW = kmax > 128 ? blk((size_t)kmax * kmax) : 0, szPW = one_shape ? 0 : blk(pws);
     double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)(d - 1) * (szP + szW + szS) + 2 * szL + szT + szQ + szSW + szPW) * 8);
     if (!ws) return TTSK_ERR_HIP;
@@ -169,14 +168,10 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
         }
         const int64_t k = kk(mu);
         double *Q = cores_out[mu];
-        rc = tall_on ? qr_cholesky_mul(Tm, sp, (int)sp, W[mu], Q, m, (int)k, stream, st, qws, sticky, beside) : 0;   // Q = qr(T W)
+        CK(gemm2(m, k, sp, Tm, sp, 1, W[mu], k, 1, Q, stream));                     // M = T W
+        rc = qr_cholesky(Q, m, k, stream, st, qws, sticky, beside);
         if (rc < 0) return rc;
-        if (rc == 0) {
-            CK(gemm2(m, k, sp, Tm, sp, 1, W[mu], k, 1, Q, stream));                 // M = T W
-            rc = qr_cholesky(Q, m, k, stream, st, qws, sticky, beside);
-            if (rc < 0) return rc;
-            if (rc == 0) { set_error("ttsk_tt_orth_sketch: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
-        }
+        if (rc == 0) { set_error("ttsk_tt_orth_sketch: QR outside the fast path"); return TTSK_ERR_UNSUPPORTED; }
         if (beside && rc == 2 && mu > 0) { set_error("ttsk_tt_orth_sketch: unexpected small unfolding"); return TTSK_ERR_UNSUPPORTED; }
         if (beside && rc != 2) {
             double *Sm = Sb + (size_t)mu * szS;
