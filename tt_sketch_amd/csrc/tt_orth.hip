@@ -6,7 +6,10 @@
 //   2. orthogonal: the d - 1 pseudo-inverses as batched launches (ttsk_pinv_batch_deferred) and W_mu = R_mu Omega_mu^+
 //      (hmt: W_mu = R_mu);
 //   3. mode by mode: T = Q-chain (x) X_mu,  M = T W_mu  (= Psi_mu Omega_mu^+ without ever forming Psi_mu),
-//      Q_mu = qr(M) by CholeskyQR2 with LAPACK's signs,  next Q-chain = Q_mu^T T  (T is formed once and used twice).
+//      Q~_mu = qr(M) by CholeskyQR2 (R's diagonal positive),  next Q-chain = Q~_mu^T T  (T is formed once and used twice);
+//   4. beside that chain, on stream + 1: LAPACK's Householder column signs of every mode (qr_signs) and, as soon as the
+//      chain has read a core for the last time, its row and column signs applied (apply_signs).
+// Also here: ttsk_tt_assemble (assemble_sketched_tt as one call).
 //
 // Nothing is read back: the verdicts of the fast factorisations accumulate in the stream's deferred flag
 // (ttsk_deferred_status); the caller repeats a rejected sketch on the robust path (ttsk_pinv / ttsk_qr_thin).
