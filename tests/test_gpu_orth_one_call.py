@@ -15,6 +15,9 @@ from oracle import ttsk_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+ONE_CALL = os.environ.get("TTSK_ORTH_ONE_CALL", "1") != "0"      # (the diagnostic switch sends everything mode by mode)
 CORE_TOL = 1e-9            # entrywise, relative to the largest entry of the core (cores went through pinv and QR)
 
 
@@ -76,7 +79,7 @@ def test_orthogonal_one_call_cores_match_oracle_and_mode_by_mode(tsa, monkeypatc
     hits = _one_call_ran(tsa, monkeypatch)
     X = tsa.TensorTrain(cores)
     one = [np.asarray(c) for c in tsa.orthogonal_sketch(X, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right).cores]
-    assert hits == [True]
+    assert hits == ([True] if ONE_CALL else [])
     monkeypatch.setattr(sketch_dispatch, "_ONE_CALL_ORTH", False)
     per_mode = [np.asarray(c) for c in tsa.orthogonal_sketch(X, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right).cores]
     want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
@@ -98,7 +101,7 @@ def test_hmt_one_call_cores_match_oracle(tsa, monkeypatch, shape, s_in, r):
     _, right = _dev_drms(tsa, shape, None, (r,) * (d - 1), None, rd)
     hits = _one_call_ran(tsa, monkeypatch)
     got = [np.asarray(c) for c in tsa.hmt_sketch(tsa.TensorTrain(cores), (r,) * (d - 1), drm=right).cores]
-    assert hits == [True]
+    assert hits == ([True] if ONE_CALL else [])
     want, _ = orc.general_sketch("tt", cores, None, rd, "hmt")
     _close(got, want)
 
@@ -114,7 +117,7 @@ def test_one_call_with_a_different_rank_in_every_mode(tsa, monkeypatch):
     right = tsa.TensorTrainDRM(r, shape, True, seed=2, cores=[np.array(c) for c in rd.cores])
     hits = _one_call_ran(tsa, monkeypatch)
     got = [np.asarray(c) for c in tsa.orthogonal_sketch(tsa.TensorTrain(cores), l, r, left_drm=left, right_drm=right).cores]
-    assert hits == [True]
+    assert hits == ([True] if ONE_CALL else [])
     want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
     _close(got, want)
 
@@ -127,7 +130,7 @@ def test_one_call_ranks_beyond_128(tsa, monkeypatch, l, r):
     left, right = _dev_drms(tsa, shape, (l,) * 2, (r,) * 2, ld, rd)
     hits = _one_call_ran(tsa, monkeypatch)
     got = [np.asarray(c) for c in tsa.orthogonal_sketch(tsa.TensorTrain(cores), (l,) * 2, (r,) * 2, left_drm=left, right_drm=right).cores]
-    assert hits == [True]
+    assert hits == ([True] if ONE_CALL else [])
     want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
     _close(got, want)
     if r <= shape[0]:                         # (the first unfolding of hmt_sketch is n_0 x r)
@@ -144,7 +147,7 @@ def test_one_call_declines_what_it_does_not_cover(tsa, monkeypatch):
     hits = _one_call_ran(tsa, monkeypatch)
     X = tsa.TensorTrain(cores)
     out = tsa.orthogonal_sketch(X, l, r, seed=2, right_drm_type=tsa.DenseGaussianDRM)
-    assert hits == [False]
+    assert hits == ([False] if ONE_CALL else [])
     assert out.error(X) < 1e-10
 def test_one_call_rejection_repeats_on_the_robust_path(tsa, monkeypatch):
     """An input of TT-rank 3 sketched with l = 8: Omega has rank 3, the normal equations are rejected on the device,
@@ -156,7 +159,7 @@ def test_one_call_rejection_repeats_on_the_robust_path(tsa, monkeypatch):
     hits = _one_call_ran(tsa, monkeypatch)
     X = tsa.TensorTrain(cores)
     out = tsa.orthogonal_sketch(X, l, r, seed=4)
-    assert hits == [True]                          # it ran, and its result was thrown away
+    assert hits == ([True] if ONE_CALL else [])    # it ran, and its result was thrown away
     assert out.error(X) < 1e-10
 
 
