@@ -7,6 +7,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import ttsk_oracle as orc  # noqa: E402
 import tt_sketch_amd as tsa  # noqa: E402
 from tt_sketch_amd import _native, tt_fused  # noqa: E402
@@ -26,6 +27,20 @@ def spy(*a, **k):
 
 
 tt_fused.try_orth_sketch = spy
+
+
+from test_gpu_c3_solves import tt_rel_diff  # noqa: E402  (|| A - B || / || B || of two TTs by a QR sweep)
+
+
+def same_tensor(got, want, what, tol=1e-9):
+    """tensor-level agreement and orthonormal left unfoldings: what holds whatever the conditioning of the unfoldings"""
+    got = [np.asarray(c) for c in got]
+    err = tt_rel_diff(got, [np.asarray(c) for c in want])
+    assert err <= tol, (what, "tensor", err)
+    for k, c in enumerate(got[:-1]):
+        q = c.reshape(-1, c.shape[2])
+        dev = np.linalg.norm(q.T @ q - np.eye(q.shape[1]))
+        assert dev <= 1e-11, (what, "orthonormality", k, dev)
 
 
 def close(got, want, tol, what):
@@ -63,14 +78,24 @@ while time.time() - t0 < budget:
     X = tsa.TensorTrain(cores)
     what = f"shape {shape} s {s_in} l {l} r {r}"
     try:
-        want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+        # entry by entry only where every unfolding is comfortably tall: the Q of a (nearly) square unfolding is known to
+        # kappa eps only, in numpy as much as here (a 15 x 15 case of this sweep differed by 1.5e-6 with the tensors equal to 1e-14)
+        kl = (1,) + l
+        tall = all(kl[mu] * shape[mu] >= 2 * l[mu] for mu in range(d - 1))
+        want, wom = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+        cond = max(np.linalg.cond(np.asarray(o)) for o in wom) if wom else 1.0      # pinv(Omega) is known to kappa eps only
+        tall = tall and cond < 1e5
         got = tsa.orthogonal_sketch(X, l, r, left_drm=left, right_drm=right).cores
-        close(got, want, 1e-7, "orthogonal " + what)
+        same_tensor(got, want, "orthogonal " + what, max(1e-9, 1e-12 * cond))
+        if tall:
+            close(got, want, 1e-7, "orthogonal " + what)
         rdh = orc.random_tt_drm(shape, l, True, rng)
         righth = tsa.TensorTrainDRM(l, shape, True, seed=3, cores=[np.array(c) for c in rdh.cores])
         want, _ = orc.general_sketch("tt", cores, None, rdh, "hmt")
         got = tsa.hmt_sketch(X, l, drm=righth).cores
-        close(got, want, 1e-7, "hmt " + what)
+        same_tensor(got, want, "hmt " + what)
+        if tall:
+            close(got, want, 1e-7, "hmt " + what)
         stt = tsa.stream_sketch(X, l, r, left_drm=left, right_drm=right)
         P, O = orc.general_sketch("tt", cores, ld, rd, "streaming")
         for direction in ("right", "left"):
@@ -80,7 +105,7 @@ while time.time() - t0 < budget:
             pairs = assemble_sketched_tt(stt.sketch_, direction=direction)
             os.environ["TTSK_ASSEMBLE_ONE_CALL"] = "1"
             close(one, pairs, 1e-8, f"assemble {direction} " + what)
-            if ref is not None:
+            if ref is not None and cond < 1e5:
                 close(one, ref, 1e-6, f"assemble-vs-oracle {direction} " + what)
     except AssertionError:
         print("FAILED", what, flush=True)
