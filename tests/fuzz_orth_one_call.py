@@ -1,5 +1,5 @@
 """Randomised sweep of the one-call orthogonal / hmt sketch and of the one-call assembly against the oracle
-(a tool, not collected by pytest):  python tests/fuzz_orth_one_call.py [seconds] [seed]"""
+(a tool, not collected by pytest):  python tests/fuzz_orth_one_call.py [seconds] [seed] [big]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from tt_sketch_amd.sketch import assemble_sketched_tt  # noqa: E402
 _native.call("ttsk_init", 0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 hits = {"one": 0, "other": 0}
 real = tt_fused.try_orth_sketch
 
@@ -53,16 +54,23 @@ def close(got, want, tol, what):
 
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
-    d = int(rng.integers(2, 7))
-    shape = tuple(int(x) for x in rng.integers(2, 40, size=d))
-    s_in = tuple(int(x) for x in rng.integers(1, 25, size=d - 1))
+    if BIG:      # few, larger cases: ranks to 200 (two-block factorisations, global-memory sign kernel), modes to 200
+        d = int(rng.integers(3, 5))
+        shape = tuple(int(x) for x in rng.integers(40, 200, size=d))
+        s_in = tuple(int(x) for x in rng.integers(30, 160, size=d - 1))
+        hi_l, hi_d = 140, 90
+    else:
+        d = int(rng.integers(2, 7))
+        shape = tuple(int(x) for x in rng.integers(2, 40, size=d))
+        s_in = tuple(int(x) for x in rng.integers(1, 25, size=d - 1))
+        hi_l, hi_d = 20, 20
     equal = rng.random() < 0.5
     if equal:
-        l = (int(rng.integers(1, 20)),) * (d - 1)
-        r = (l[0] + int(rng.integers(1, 20)),) * (d - 1)
+        l = (int(rng.integers(1, hi_l)),) * (d - 1)
+        r = (l[0] + int(rng.integers(1, hi_d)),) * (d - 1)
     else:
-        l = tuple(int(x) for x in rng.integers(1, 20, size=d - 1))
-        r = tuple(x + int(y) for x, y in zip(l, rng.integers(1, 20, size=d - 1)))
+        l = tuple(int(x) for x in rng.integers(1, hi_l, size=d - 1))
+        r = tuple(x + int(y) for x, y in zip(l, rng.integers(1, hi_d, size=d - 1)))
     # the reference trims sketch ranks to what the unfoldings allow
     l = tuple(tsa.utils.process_tt_rank(l, shape, trim=True))
     r = tuple(tsa.utils.process_tt_rank(r, shape, trim=True))
