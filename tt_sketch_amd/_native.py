@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
                     c_size_t, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttsk.so")
+LIB_PATH = os.environ.get("TTSK_LIB") or os.path.join(_HERE, "libttsk.so")      # TTSK_LIB: another build of the library (A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
 
 TTSK_ERR_ARG = -2

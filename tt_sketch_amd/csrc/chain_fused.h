@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         // look-ahead of a run's last k-block, reads the rows behind the W image: finite, unused)
         auto wfetch = [&](const double *wrun, int u, double (&f)[NQF ? NQF : 1], double (&g)[STRQ ? STRQ : 1]) {
 #pragma unroll
-            for (int p = 0; p < NQF; ++p) f[p] = wrun[wl_lane + u * 4 * AP + 32 * p];
+            for (int p = 0; p < NQF; ++p) f[p] = LDS_UNPAIRED(wrun[wl_lane + u * 4 * AP + 32 * p]);
 #pragma unroll
             for (int q = 0; q < STRQ; ++q) g[q] = wrun[ws_lane + u * 4 * AP + 8 * q];
         };
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
             asm volatile("" : "+v"(el0), "+v"(es0));
             auto efetch = [&](int kap, double (&f)[NNF ? NNF : 1], double (&g)[STRN ? STRN : 1]) {
 #pragma unroll
-                for (int nn = 0; nn < NNF; ++nn) f[nn] = eb[el0 + kap * 4 * A2P + 32 * nn];
+                for (int nn = 0; nn < NNF; ++nn) f[nn] = LDS_UNPAIRED(eb[el0 + kap * 4 * A2P + 32 * nn]);
 #pragma unroll
                 for (int q = 0; q < STRN; ++q) g[q] = eb[es0 + kap * 4 * A2P + 8 * q];
             };

@@ -122,7 +122,7 @@ __device__ __forceinline__ void cw_compute(const ChainWide &a, const double *Wl,
         double af[NQF ? NQF : 1], sf[STRQ ? STRQ : 1];
         auto wfetch = [&](const double *wrun, int u, double (&f)[NQF ? NQF : 1], double (&g)[STRQ ? STRQ : 1]) {
 #pragma unroll
-            for (int p = 0; p < NQF; ++p) f[p] = wrun[wl_lane + u * 4 * AP + 32 * p];
+            for (int p = 0; p < NQF; ++p) f[p] = LDS_UNPAIRED(wrun[wl_lane + u * 4 * AP + 32 * p]);
 #pragma unroll
             for (int q = 0; q < STRQ; ++q) g[q] = wrun[ws_lane + u * 4 * AP + 8 * q];
         };
@@ -184,7 +184,7 @@ __device__ __forceinline__ void cw_compute(const ChainWide &a, const double *Wl,
             asm volatile("" : "+v"(el0), "+v"(es0));
             auto efetch = [&](int kap, double (&f)[NNF ? NNF : 1], double (&g)[STRN ? STRN : 1]) {
 #pragma unroll
-                for (int nn = 0; nn < NNF; ++nn) f[nn] = eb[el0 + kap * 4 * A2P + 32 * nn];
+                for (int nn = 0; nn < NNF; ++nn) f[nn] = LDS_UNPAIRED(eb[el0 + kap * 4 * A2P + 32 * nn]);
 #pragma unroll
                 for (int q = 0; q < STRN; ++q) g[q] = eb[es0 + kap * 4 * A2P + 8 * q];
             };

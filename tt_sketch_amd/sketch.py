@@ -23,7 +23,7 @@ from .sketch_dispatch import SketchMethod, general_sketch
 from .sketching_methods.abstract_methods import (CansketchCP, CansketchDense, CansketchSparse,
                                                  CansketchTT)
 from .tensor import Tensor, TensorTrain
-from .utils import ArrayList, TTRank, pinv_dev_many, process_tt_rank
+from .utils import ArrayList, TTRank, pinv_dev_many, process_tt_rank, refine_left, refine_right
 
 DEFAULT_DRM = {
     CansketchDense: DenseGaussianDRM,
@@ -326,7 +326,10 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool
             st = k % nstreams
             Pc, Oi = P.contiguous(st), pinvs[k]
             keep += [Pc, Oi]
-            pending.append(contract("ij,jk->ik", Pc.reshape(r1 * n, r2), Oi, stream=st).reshape(r1, n, O.shape[0]))
+            M = Pc.reshape(r1 * n, r2)
+            Oc = as_dev(O, st).contiguous(st)
+            keep.append(Oc)
+            pending.append(refine_right(contract("ij,jk->ik", M, Oi, stream=st), M, Oc, Oi, stream=st).reshape(r1, n, O.shape[0]))
         pending.append(Psi[-1])
     elif direction == "left":
         pending.append(Psi[0])
@@ -335,7 +338,10 @@ def assemble_sketched_tt(sketch: SketchContainer, direction="auto", device: bool
             st = k % nstreams
             Pc, Oi = P.contiguous(st), pinvs[k]
             keep += [Pc, Oi]
-            pending.append(contract("ij,jk->ik", Oi, Pc.reshape(r1, n * r2), stream=st).reshape(O.shape[1], n, r2))
+            M = Pc.reshape(r1, n * r2)
+            Oc = as_dev(O, st).contiguous(st)
+            keep.append(Oc)
+            pending.append(refine_left(contract("ij,jk->ik", Oi, M, stream=st), Oc, M, Oi, stream=st).reshape(O.shape[1], n, r2))
     else:
         raise ValueError(f"Unknown direction {direction}")
     sync()
