@@ -229,7 +229,53 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
     } else {
         batched = false;
     }
+    // "right" direction, pseudo-inverses batched, interior modes of one size: their products (and the refinement's) as
+    // batched launches on `stream` as well -- 3 launches + the copies instead of 3 per pair
+    std::vector<char> grouped(d - 1, 0);
+    if (batched && direction == 0 && d - 1 >= 3) {
+        std::vector<int> G;
+        for (int k = 1; k < d - 1; ++k)
+            if (n[k] == n[1] && psi[k] && cores_out[k]) G.push_back(k);
+        const int nb = (int)G.size();
+        const int64_t m = lr[0] * n[1], l = lr[0], r = rr[0];
+        if (nb >= 2 && nb <= SK_MAXB) {
+            double *Rall = refine ? (double *)scratch(stream, SCRATCH_ORTH, (size_t)nb * m * r * 8) : nullptr;
+            if (refine && !Rall) return TTSK_ERR_HIP;
+            const double *A[SK_MAXB], *B[SK_MAXB], *Om[SK_MAXB], *Rc[SK_MAXB];
+            double *C[SK_MAXB], *R[SK_MAXB];
+            for (int b = 0; b < nb; ++b) {
+                A[b] = psi[G[b]]; B[b] = work[G[b]]; C[b] = cores_out[G[b]]; Om[b] = omega[G[b]];
+                R[b] = Rall ? Rall + (size_t)b * m * r : nullptr; Rc[b] = R[b];
+            }
+            auto desc = [](int64_t M, int64_t N, int64_t K, double alpha, int acc) {
+                ttsk_gemm_desc g{};
+                g.batch = 1; g.M = M; g.N = N; g.Ko = 1; g.Ki = K;
+                g.a_m = K; g.a_ki = 1; g.b_ki = N; g.b_n = 1; g.c_m = N; g.c_n = 1; g.alpha = alpha; g.accumulate = acc;
+                return g;
+            };
+            rc = skinny_try_batch(desc(m, l, r, 1.0, 0), nb, A, B, C, stream, st);                       // C = Psi P
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                for (int b = 0; b < nb; ++b) grouped[G[b]] = 1;
+                if (refine) {
+                    for (int b = 0; b < nb; ++b)
+                        TTSK_HIP(hipMemcpyAsync(R[b], A[b], (size_t)m * r * 8, hipMemcpyDeviceToDevice, st));
+                    const double *Cc[SK_MAXB];
+                    for (int b = 0; b < nb; ++b) Cc[b] = C[b];
+                    rc = skinny_try_batch(desc(m, r, l, -1.0, 1), nb, Cc, Om, R, stream, st);           // R = Psi - C Omega
+                    if (rc < 0) return rc;
+                    if (rc == 0)
+                        for (int b = 0; b < nb; ++b) CK(gemm2(m, r, l, C[b], l, 1, Om[b], r, 1, R[b], stream, -1.0, 1));
+                    rc = skinny_try_batch(desc(m, l, r, 1.0, 1), nb, Rc, B, C, stream, st);              // C += R P
+                    if (rc < 0) return rc;
+                    if (rc == 0)
+                        for (int b = 0; b < nb; ++b) CK(gemm2(m, l, r, R[b], r, 1, B[b], l, 1, C[b], stream, 1.0, 1));
+                }
+            }
+        }
+    }
     for (int k = 0; k < d - 1; ++k) {
+        if (grouped[k]) continue;
         const int q = (stream + k) % TTSK_NUM_STREAMS;
         if (k < nstreams && q != stream) CK(ttsk_stream_wait(q, stream));        // fork
         if (!batched) {
@@ -250,7 +296,7 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
             TTSK_ARG(psi[k] && cores_out[k], "ttsk_tt_assemble: NULL core %d", k);
             CK(gemm2(m, lr[k], rr[k], psi[k], rr[k], 1, work[k], lr[k], 1, cores_out[k], q));
             if (refine) {
-                double *R = (double *)scratch(q, SCRATCH_ORTH, (size_t)m * rr[k] * 8);
+                double *R = (double *)scratch(q, SCRATCH_DRIVER, (size_t)m * rr[k] * 8);
                 if (!R) return TTSK_ERR_HIP;
                 TTSK_HIP(hipMemcpyAsync(R, psi[k], (size_t)m * rr[k] * 8, hipMemcpyDeviceToDevice, stream_of(q)));
                 CK(gemm2(m, rr[k], lr[k], cores_out[k], lr[k], 1, omega[k], rr[k], 1, R, q, -1.0, 1));       // R = Psi - C Omega
@@ -262,7 +308,7 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
             TTSK_ARG(psi[k + 1] && cores_out[k + 1], "ttsk_tt_assemble: NULL core %d", k + 1);
             CK(gemm2(rr[k], cols, lr[k], work[k], lr[k], 1, psi[k + 1], cols, 1, cores_out[k + 1], q));
             if (refine) {
-                double *R = (double *)scratch(q, SCRATCH_ORTH, (size_t)lr[k] * cols * 8);
+                double *R = (double *)scratch(q, SCRATCH_DRIVER, (size_t)lr[k] * cols * 8);
                 if (!R) return TTSK_ERR_HIP;
                 TTSK_HIP(hipMemcpyAsync(R, psi[k + 1], (size_t)lr[k] * cols * 8, hipMemcpyDeviceToDevice, stream_of(q)));
                 CK(gemm2(lr[k], cols, rr[k], omega[k], rr[k], 1, cores_out[k + 1], cols, 1, R, q, -1.0, 1)); // R = Psi - Omega C
