@@ -204,3 +204,54 @@ def test_assemble_one_call_matches_the_pair_by_pair_path(tsa, monkeypatch, direc
         assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
     rec = tsa.TensorTrain(one)
     assert rec.error(X) < 1e-9
+
+
+@pytest.mark.parametrize("direction", ["right", "left"])
+def test_assembly_matches_lstsq_for_ill_conditioned_omega(tsa, monkeypatch, direction):
+    """Omega with singular values from 1 down to 1e-4 (what the sketches of TT-GMRES iterates look like): the assembled
+    tensor agrees with scipy.linalg.lstsq -- the reference's solve, utils.py:98-109 -- to 1e-11 on BOTH assembly paths.
+    A product with an explicitly formed pseudo-inverse alone is off by about 1e-10 here (kappa * eps on every component,
+    where lstsq loses it only along the small singular directions) (the refinement step of
+    ttsk_tt_assemble / utils.refine_right)."""
+    import scipy.linalg
+    from test_gpu_c3_solves import tt_rel_diff
+    from tt_sketch_amd.sketch import assemble_sketched_tt
+    from tt_sketch_amd.sketch_container import SketchContainer
+    rng = np.random.default_rng(17)
+    n, l, r, d = (40, 50, 60, 30), 12, 20, 4
+    if direction == "left":
+        l, r = r, l
+    k = min(l, r)
+    Om, Psi = [], []
+    for mu in range(d - 1):
+        U, _ = np.linalg.qr(rng.standard_normal((l, k)))
+        V, _ = np.linalg.qr(rng.standard_normal((r, k)))
+        Om.append((U * np.logspace(0, -4, k)) @ V.T)
+    for mu in range(d):
+        r1, r2 = (1 if mu == 0 else l), (1 if mu == d - 1 else r)
+        P = rng.standard_normal((r1, n[mu], r2))
+        # consistent with its Omega (rows / columns in Omega's row / column space), as the Psi of a sketch are
+        if direction == "right" and mu < d - 1:
+            P = np.einsum("ajl,lr->ajr", rng.standard_normal((r1, n[mu], l)), Om[mu])
+        if direction == "left" and mu > 0:
+            P = np.einsum("lr,rjb->ljb", Om[mu - 1], rng.standard_normal((r, n[mu], r2)))
+        Psi.append(P)
+    want = []
+    if direction == "right":
+        for P, O in zip(Psi[:-1], Om):
+            r1, nn, r2 = P.shape
+            want.append(scipy.linalg.lstsq(O.T, P.reshape(r1 * nn, r2).T, cond=None)[0].T.reshape(r1, nn, -1))
+        want.append(Psi[-1])
+    else:
+        want.append(Psi[0])
+        for P, O in zip(Psi[1:], Om):
+            r1, nn, r2 = P.shape
+            want.append(scipy.linalg.lstsq(O, P.reshape(r1, nn * r2), cond=None)[0].reshape(-1, nn, r2))
+    sk = SketchContainer([np.array(p) for p in Psi], [np.array(o) for o in Om])
+    one = [np.asarray(c) for c in assemble_sketched_tt(sk, direction=direction)]
+    e_one = tt_rel_diff(one, want)
+    monkeypatch.setenv("TTSK_ASSEMBLE_ONE_CALL", "0")
+    pairs = [np.asarray(c) for c in assemble_sketched_tt(sk, direction=direction)]
+    e_pairs = tt_rel_diff(pairs, want)
+    print("assembly vs lstsq:", e_one, e_pairs)
+    assert e_one < 1e-11 and e_pairs < 1e-11
