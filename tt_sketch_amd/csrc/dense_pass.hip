@@ -1,0 +1,260 @@
+// The pass over a dense tensor that a sketch with tensor-train DRMs starts with (reference dense_sketch.py:7-52 with the
+// matrices of tensor_train_drm.py:109-122): BOTH products that read the tensor, from ONE read of it.
+//
+//   X[b][q][t]    the tensor, b = first mode (NB = 32 or 64), t = last mode (T), q = everything in between (Q), C order
+//   Z[p'][q][t] = sum_b C[b][p'] X[b][q][t]        the first left product, C the left DRM's first core (NB x ll), ll <= 20
+//   U[b][p][t]  = sum_q P[q][p]  X[b][q][t]        the long-K half of Psi_0, P the right DRM's matrix of one core less (Q x r),
+//                                                   r <= 40 (Psi_0 = U x last core follows as a small product)
+//
+// Z needs every b of a column in one workgroup, U sums over q: a workgroup owns 16 values of t (128-byte pieces of the tensor's
+// rows: whole cache lines) and a range of q, for all b.  Its eight waves hold U for NB / 8 values of b each -- (2 tiles + 2
+// four-wide strips) x NB / 8 accumulators of v_mfma_f64_16x16x4 / 4x4x4, 160 registers at NB = 64 -- and walk q in steps of 8:
+// a (NB x 8 x 16) tile of X (64 KB) goes to LDS by global_load_lds, double-buffered, and is read twice from there, once with
+// q as the K index of the matrix instruction (U: lanes (t, q)), once with b as the K index (Z: lanes (t, b), wave w takes
+// row q0 + w and chains over all b).  Row q of b's chunk sits at row q ^ (b & 1): both fragment shapes then read 32
+// consecutive doubles per half wave.  The tensor is read once (8.59 GB at C2 instead of 17.2), Z is written once, the
+// partial U of the q ranges are summed by a second launch.
+//
+// Work per tile at NB = 64: U 64 x (2 x 64 + 2 x 16) + Z 8 x 16 x (64 + 16) = 20480 cycles of the matrix pipes per 64 KB
+// = 129 GF per C2 sketch (no padded rows: 20 = 16 + 4, 40 = 32 + 2 x 4), 1.64 ms at the fp64 peak; the HBM side is
+// 8.59 + 2.68 GB = 2.1 ms at the 5.5 TB/s a mixed stream reaches.
+#include "common.h"
+
+namespace ttsk {
+
+namespace {
+
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double mfma4s(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+struct DensePass {
+    const double *X;
+    int64_t sb;            // elements between consecutive b
+    int Q, T;
+    const double *C;
+    int ll;
+    const double *P;
+    int r;
+    double *Z;
+    double *slab;          // [workgroup][NB][10][64]: the accumulators as the lanes hold them
+    int nt, nqc;           // t ranges (T / 16), q chunks (a multiple of 8)
+};
+
+constexpr int DP_PROW = 48;        // doubles per row of the P image (40 used; 48 = 96 dwords: rows kq, kq + 1 on disjoint banks)
+
+template <int NBW>
+__global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
+{
+    constexpr int NB = 8 * NBW;
+    extern __shared__ double lds[];
+    double *Xl = lds;                          // [2][NB][8][16]
+    double *Pl = Xl + 2 * NB * 128;            // [2][8][DP_PROW]
+    double *Cf = Pl + 2 * 8 * DP_PROW;         // [NB][16]   columns 0..15 of C
+    double *Cs = Cf + NB * 16;                 // [NB][4]    columns 16..19
+
+    const int tid = threadIdx.x, lane = tid & 63, x16 = lane & 15, kq = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    // the nt workgroups that share the 512-byte rows of a q range sit on one XCD (ids 8 apart) next to each other in time
+    const int tr = (id >> 3) % a.nt, qc = (id & 7) + 8 * (id / (8 * a.nt));
+    const int t0 = 16 * tr;
+    const int total = a.Q >> 3;
+    const int it_beg = (int)((int64_t)qc * total / a.nqc), it_end = (int)((int64_t)(qc + 1) * total / a.nqc);
+
+    for (int e = tid; e < NB * 20; e += 512) {
+        const int b = e / 20, c = e - 20 * b;
+        const double v = c < a.ll ? a.C[(int64_t)b * a.ll + c] : 0.0;
+        if (c < 16) Cf[b * 16 + c] = v; else Cs[b * 4 + c - 16] = v;
+    }
+
+    // tile `it` -> image `buf`: wave w brings the chunks of its own NBW values of b (one 1 KB instruction each), waves 0..2 the
+    // 8 rows of P (24 16-byte units per row, the last 4 of them padding: whatever they read is never used)
+    // (addresses as a wave-uniform 64-bit base plus a 32-bit lane offset: the saddr form of the instructions, two registers per
+    // lane for all of them -- left to itself the compiler keeps a 64-bit address per lane and chunk and spills the accumulators)
+    const int xrow = lane >> 3, xcol = 2 * (lane & 7);
+    const uint32_t xoff0 = (uint32_t)((xrow * a.T + xcol) * 8), xoff1 = (uint32_t)(((xrow ^ 1) * a.T + xcol) * 8);
+    const int pU = 64 * w + lane, prow = pU / 24, ppair = pU - 24 * prow;
+    const uint32_t poff = (uint32_t)((prow * a.r + (2 * ppair + 2 <= a.r ? 2 * ppair : 0)) * 8);
+    const char *xbase = (const char *)a.X + ((int64_t)w * NBW * a.sb + t0) * 8;
+    auto issue = [&](int it, int buf) {
+        const int64_t tile = uniform_i64((int64_t)it * 8 * a.T * 8);
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) {
+            const char *src = xbase + uniform_i64(tile + (int64_t)u * a.sb * 8) + ((u & 1) ? xoff1 : xoff0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(Xl + (buf * NB + w * NBW + u) * 128), 16, 0, 0);
+        }
+        if (w < 3) {
+            const char *src = (const char *)a.P + uniform_i64((int64_t)it * 8 * a.r * 8) + poff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(Pl + buf * 8 * DP_PROW + w * 128), 16, 0, 0);
+        }
+    };
+
+    v4d acc[NBW][2];
+    double accs[NBW][2];
+#pragma unroll
+    for (int bi = 0; bi < NBW; ++bi)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            accs[bi][p] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[bi][p][j] = 0.0;
+        }
+
+    // Z of the previous tile, stored while the next one is computed (its completion is awaited one tile later, not at once)
+    v4d zp;
+    double zps = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zp[j] = 0.0;
+    const int64_t zs_row = (int64_t)a.Q * a.T;
+    const uint32_t zoff = (uint32_t)((kq * zs_row + x16) * 8);          // 3 Q T doubles at most: the host checks the range
+    auto store_z = [&](int it) {
+        const int64_t at = uniform_i64((((int64_t)it * 8 + w) * a.T + t0) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (kq + 4 * j < a.ll) *(double *)((char *)a.Z + uniform_i64(at + 4 * j * zs_row * 8) + zoff) = zp[j];
+        if (16 + kq < a.ll) *(double *)((char *)a.Z + uniform_i64(at + 16 * zs_row * 8) + zoff) = zps;
+    };
+
+    if (it_beg < it_end) issue(it_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = it_beg; it < it_end; ++it) {
+        const int buf = (it - it_beg) & 1;
+        if (it + 1 < it_end) issue(it + 1, buf ^ 1);        // that image was last read before the barrier just passed
+        if (it > it_beg) store_z(it - 1);
+        const double *xb = Xl + buf * NB * 128, *pb = Pl + buf * 8 * DP_PROW;
+
+        // ---- U: q is the K index; this wave's NBW values of b
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 4 * j + kq;
+            const double *pr = pb + row * DP_PROW;
+            const double pf0 = pr[x16], pf1 = pr[16 + x16], ps0 = pr[32 + (x16 & 3)], ps1 = pr[36 + (x16 & 3)];
+#pragma unroll
+            for (int bi = 0; bi < NBW; ++bi) {
+                const double xf = xb[(w * NBW + bi) * 128 + (row ^ (bi & 1)) * 16 + x16];
+                acc[bi][0] = mfma16(xf, pf0, acc[bi][0]);
+                acc[bi][1] = mfma16(xf, pf1, acc[bi][1]);
+                accs[bi][0] = mfma4s(xf, ps0, accs[bi][0]);
+                accs[bi][1] = mfma4s(xf, ps1, accs[bi][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // fragments of one block at a time: the accumulators leave room for no more
+        }
+
+        // ---- Z: b is the K index; row q0 + w of the tile, two chains
+        v4d z0, z1;
+        double zs0 = 0.0, zs1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { z0[j] = 0.0; z1[j] = 0.0; }
+        const double *xz = xb + kq * 128 + (w ^ (kq & 1)) * 16 + x16;
+        const double *cf = Cf + kq * 16 + x16, *cs = Cs + kq * 4 + (x16 & 3);
+#pragma unroll
+        for (int k4 = 0; k4 < NB / 4; k4 += 2) {
+            const double xa = xz[k4 * 512], xc = xz[(k4 + 1) * 512];
+            z0 = mfma16(cf[k4 * 64], xa, z0);
+            zs0 = mfma4s(cs[k4 * 16], xa, zs0);
+            z1 = mfma16(cf[(k4 + 1) * 64], xc, z1);
+            zs1 = mfma4s(cs[(k4 + 1) * 16], xc, zs1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zp[j] = z0[j] + z1[j];
+        zps = zs0 + zs1;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (and the Z stores are done)
+        __syncthreads();
+    }
+    if (it_end > it_beg) store_z(it_end - 1);
+
+    // the accumulators as they are: [b][slot][lane], slot = 4 * tile + register, 8 + strip
+    double *out = a.slab + ((int64_t)id * NB + w * NBW) * 640 + lane;
+#pragma unroll
+    for (int bi = 0; bi < NBW; ++bi) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(bi * 10 + 4 * p + j) * 64] = acc[bi][p][j];
+        out[(bi * 10 + 8) * 64] = accs[bi][0];
+        out[(bi * 10 + 9) * 64] = accs[bi][1];
+    }
+}
+
+// U[b][p][t] = sum over the q chunks; one thread per accumulator element of a t range
+__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int nt, int nqc, int T, int r, double *U)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per = NB * 640;
+    if (e >= (int64_t)per * nt) return;
+    const int tr = (int)(e / per), f = (int)(e - (int64_t)tr * per);
+    const int b = f / 640, slot = (f - 640 * b) >> 6, l = f & 63;
+    double s = 0.0;
+    for (int qc = 0; qc < nqc; ++qc) {
+        const int id = (qc & 7) + 8 * (tr + nt * (qc >> 3));
+        s += slab[(int64_t)id * per + f];
+    }
+    int p, t;
+    if (slot < 8) {                       // 16x16x4: register j of lane l is row (l >> 4) + 4 j, column l & 15
+        p = 16 * (slot >> 2) + (l & 15);
+        t = (l >> 4) + 4 * (slot & 3);
+    } else {                              // 4x4x4: lane (i = l >> 4, beta = (l >> 2) & 3, c = l & 3) is row 4 beta + i, column c
+        p = 32 + 4 * (slot - 8) + (l & 3);
+        t = 4 * ((l >> 2) & 3) + (l >> 4);
+    }
+    if (p < r) U[((int64_t)b * r + p) * T + 16 * tr + t] = s;
+}
+
+}  // namespace
+
+}  // namespace ttsk
+
+extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int64_t T, const double *C, int64_t ll,
+                                     const double *P, int64_t r, double *Z, double *U, int stream)
+{
+    using namespace ttsk;
+    TTSK_ARG(X && C && P && Z && U, "ttsk_dense_first_pass: NULL operand");
+    TTSK_ARG(n0 > 0 && Q > 0 && T > 0 && ll > 0 && r > 0, "ttsk_dense_first_pass: empty extent");
+    static const int on = [] { const char *e = getenv("TTSK_DENSE_ONE_PASS"); return e ? atoi(e) : 1; }();
+    if (!on || (n0 != 32 && n0 != 64) || (T & 15) || (Q & 7) || ll > 20 || r > 40 || (r & 1) || Q * T >= (1ll << 27) ||
+        (((uintptr_t)X | (uintptr_t)P) & 15)) {
+        set_error("ttsk_dense_first_pass: shape outside the kernel's cover (first mode 32 or 64, last mode a multiple of 16, "
+                  "middle extent a multiple of 8, left rank <= 20, even right rank <= 40)");
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    TTSK_STREAM(st, stream);
+    const int nt = (int)(T / 16);
+    int64_t nqc = 8 * std::max<int64_t>(1, 32 / nt);
+    nqc = std::min<int64_t>(nqc, 8 * cdiv(Q / 8, 8));          // at least one tile for most chunks
+    const int NB = (int)n0;
+    const int64_t grid = (int64_t)nt * nqc;
+    double *slab = (double *)scratch(stream, SCRATCH_MISC, (size_t)grid * NB * 640 * 8);
+    if (!slab) return TTSK_ERR_HIP;
+    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, Z, slab, nt, (int)nqc};
+    const size_t lds = (size_t)(2 * NB * 128 + 2 * 8 * DP_PROW + NB * 20) * 8;
+    static bool attr = false;
+    if (!attr) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        attr = true;
+    }
+    if (prof_on()) prof_open_named(st, PROF_SOLVE, 0.0, "dense_pass");
+    if (NB == 64)
+        hipLaunchKernelGGL(dense_pass_kernel<8>, dim3((unsigned)grid), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL(dense_pass_kernel<4>, dim3((unsigned)grid), dim3(512), lds, st, a);
+    TTSK_LAUNCH_CHECK();
+    const int64_t elems = (int64_t)NB * 640 * nt;
+    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, nt, (int)nqc, (int)T, (int)r, U);
+    TTSK_LAUNCH_CHECK();
+    if (prof_on()) prof_close(st);
+    return TTSK_OK;
+}
