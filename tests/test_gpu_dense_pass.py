@@ -30,7 +30,7 @@ def _rel(a, b):
 # (n0, Q, T, ll, r): one tile; several tiles per q range (ragged); every t range count; ranks below / at the tile edges
 SHAPES = [(32, 8, 16, 20, 40), (64, 8, 16, 20, 40), (64, 24, 32, 20, 40), (32, 4096, 16, 20, 40), (64, 8000, 32, 20, 40),
           (32, 40, 48, 7, 22), (64, 16, 64, 16, 32), (32, 72, 128, 17, 34), (64, 264, 64, 3, 2), (64, 8, 16, 1, 40),
-          (32, 16, 256, 20, 38), (64, 4, 16, 20, 40), (32, 2052, 16, 9, 12)]
+          (32, 16, 256, 20, 38), (64, 16, 16, 20, 40), (32, 2056, 16, 9, 12)]
 
 
 @pytest.mark.parametrize("n0,Q,T,ll,r", SHAPES)
