@@ -23,7 +23,7 @@ import sys
 import pandas as pd
 
 NAMES = (r"((?:gemm_f64_kernel|skinny_s_kernel|skinny_r_kernel|chain_step_kernel|chain_wide_kernel|stream_small_kernel|"
-         r"sample_rows_kernel|sample_kernel|sparse_psi_mfma_kernel)<[^>]*>|splitk_reduce_kernel|skinny_r_reduce2?|small_gemm_kernel|"
+         r"sample_rows_kernel|sample_kernel|sparse_psi_mfma_kernel|dense_pass_kernel)<[^>]*>|dense_pass_reduce|dense_pass_zsum|splitk_reduce_kernel|skinny_r_reduce2?|small_gemm_kernel|"
          r"sg_pass_kernel|sg_psi_reduce_kernel|sg_om_reduce_kernel|expand_rows_kernel|chol_inv_kernel|hh_sign_scale_kernel)")
 
 

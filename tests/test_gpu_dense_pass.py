@@ -30,7 +30,9 @@ def _rel(a, b):
 # (n0, Q, T, ll, r): one tile; several tiles per q range (ragged); every t range count; ranks below / at the tile edges
 SHAPES = [(32, 8, 16, 20, 40), (64, 8, 16, 20, 40), (64, 24, 32, 20, 40), (32, 4096, 16, 20, 40), (64, 8000, 32, 20, 40),
           (32, 40, 48, 7, 22), (64, 16, 64, 16, 32), (32, 72, 128, 17, 34), (64, 264, 64, 3, 2), (64, 8, 16, 1, 40),
-          (32, 16, 256, 20, 38), (64, 16, 16, 20, 40), (32, 2056, 16, 9, 12)]
+          (32, 16, 256, 20, 38), (64, 16, 16, 20, 40), (32, 2056, 16, 9, 12),
+          # first mode beyond 64: blocks of 64 with partial Z (what the second pair of a sketch runs on)
+          (128, 16, 16, 20, 40), (192, 40, 32, 7, 22), (1280, 64, 64, 20, 40), (640, 512, 16, 20, 40)]
 
 
 @pytest.mark.parametrize("n0,Q,T,ll,r", SHAPES)
@@ -55,7 +57,7 @@ def test_first_pass_declines_outside_its_cover(tsa, bad):
     from tt_sketch_amd import _native as nat
     from tt_sketch_amd.device import DevArray
     n0, Q, T, ll, r = 32, 16, 16, 20, 40
-    if bad == "n0": n0 = 48
+    if bad == "n0": n0 = 96
     if bad == "T": T = 24
     if bad == "Q": Q = 10
     if bad == "ll": ll = 21
@@ -68,9 +70,11 @@ def test_first_pass_declines_outside_its_cover(tsa, bad):
         nat.call("ttsk_dense_first_pass", V(X.ptr), n0, Q, T, V(C.ptr), ll, V(P.ptr), r, V(Z.ptr), V(U.ptr), 0)
 
 
-@pytest.mark.parametrize("shape,l,r", [((32, 16, 4, 6), 5, 8), ((64, 32, 8), 20, 40), ((32, 16, 5, 8, 3), 6, 10),
-                                        ((32, 48, 6, 4), (4, 7, 9), (12, 10, 6)), ((64, 16, 16, 16), 20, 40)])
-def test_dense_sketch_with_the_first_pass_vs_oracle(tsa, monkeypatch, shape, l, r):
+@pytest.mark.parametrize("shape,l,r,second", [((32, 16, 4, 6), 5, 8, False), ((64, 32, 8), 20, 40, False),
+                                               ((32, 16, 5, 8, 3), 6, 10, False), ((32, 48, 6, 4), (4, 7, 9), (12, 10, 6), False),
+                                               ((64, 16, 16, 16), 20, 40, True), ((32, 16, 16, 8), 4, 8, True),
+                                               ((32, 16, 16, 8, 2), (8, 5, 3, 2), (6, 10, 12, 14), True)])
+def test_dense_sketch_with_the_first_pass_vs_oracle(tsa, monkeypatch, shape, l, r, second):
     """general_sketch of a DenseTensor with TensorTrainDRMs whose first two modes put it on the one-pass kernel (the right
     DRM's matrix meets the tensor's columns position by position, so its outermost core carries the size of mode 1): every
     Psi and Omega against the oracle's dense path (1e-11), and against the device path with the kernel switched off."""
@@ -84,8 +88,10 @@ def test_dense_sketch_with_the_first_pass_vs_oracle(tsa, monkeypatch, shape, l, 
     calls = []
     orig = dense_sketch._first_pass
     monkeypatch.setattr(dense_sketch, "_first_pass", lambda *a: calls.append(orig(*a)) or calls[-1])
+    monkeypatch.setattr(dense_sketch, "_PAIR_MIN_BYTES", 0)          # the second pair through the kernel too, where it fits
     sk = tsa.general_sketch(tsa.DenseTensor(X), left, right, tsa.SketchMethod.streaming)
-    assert calls == [True]                                   # the kernel took it
+    assert calls[0] is True                                  # the kernel took the pass over the tensor
+    assert calls[1] is second                                # ... and Z_1 / Psi_1 over Z_0 where the shape allows
     oP, oO = orc.general_sketch("dense", X, ld, rd, "streaming")
     for got, want in zip(list(sk.Psi_cores) + list(sk.Omega_mats), list(oP) + list(oO)):
         assert np.asarray(got).shape == np.asarray(want).shape and _rel(got, want) < 1e-11

@@ -1,7 +1,8 @@
 // The pass over a dense tensor that a sketch with tensor-train DRMs starts with (reference dense_sketch.py:7-52 with the
 // matrices of tensor_train_drm.py:109-122): BOTH products that read the tensor, from ONE read of it.
 //
-//   X[b][q][t]    the tensor, b = first mode (NB = 32 or 64), t = last mode (T), q = everything in between (Q), C order
+//   X[b][q][t]    the tensor, b = first mode (32, or a multiple of 64: blocks of NB = 64), t = last mode (T), q = everything in
+//                 between (Q), C order
 //   Z[p'][q][t] = sum_b C[b][p'] X[b][q][t]        the first left product, C the left DRM's first core (NB x ll), ll <= 20
 //   U[b][p][t]  = sum_q P[q][p]  X[b][q][t]        the long-K half of Psi_0, P the right DRM's matrix of one core less (Q x r),
 //                                                   r <= 40 (Psi_0 = U x last core follows as a small product)
@@ -16,6 +17,11 @@
 // wave (SQ_LDS_BANK_CONFLICT = 0).  The next tile's loads are issued behind the first two steps of a tile, so that the matrix
 // pipes start right behind the barrier -- which carries no fence.  The tensor is read once (8.59 GB at C2 instead of 17.2), Z
 // is written once, the partial U of the q ranges are summed by a second launch.
+//
+// The second pair of a sketch -- Z_1 and Psi_1 from Z_0, whose rows are (p', i_1): 1280 at C2 -- is the same two sums one level down:
+// a first mode beyond 64 runs as blocks of 64 values of b (blockIdx = block * (t ranges * q ranges) + ...), U per block as it is,
+// Z as one partial sum per block (scratch) that a third launch adds up: 2.7 GB read once + 0.84 GB of partial Z instead of 2.7 GB
+// read twice (C2: 1.7 -> 1.27 ms).
 //
 // Work per tile at NB = 64: U 2 x 64 x (2 x 64 + 2 x 16) + Z 8 x 16 x (64 + 16) = 30720 cycles of the matrix pipes per 64 KB
 // = 129 GF per C2 sketch (no padded rows: 20 = 16 + 4, 40 = 32 + 2 x 4), 1.64 ms at the fp64 peak (SQ_VALU_MFMA_BUSY_CYCLES
@@ -51,6 +57,7 @@ struct DensePass {
     double *Z;
     double *slab;          // [workgroup][NB][10][64]: the accumulators as the lanes hold them
     int nt, nqc;           // t ranges (T / 16), q chunks (a multiple of 8)
+    int64_t zblock;        // first mode beyond 64: blocks of 64 values of b, blockIdx = block * nt * nqc + ...; block k's partial Z at Z + k * zblock
     int dbg;               // diagnostics (TTSK_DP_DBG): 1 = no tile loads after the first, 2 = no Z stores, 4 = no rotated start
 };
 
@@ -69,16 +76,16 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 
     const int tid = threadIdx.x, lane = tid & 63, x16 = lane & 15, kq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = blockIdx.x;
+    const int id = blockIdx.x, per_block = a.nt * a.nqc, bb = id / per_block, idl = id - bb * per_block;
     // the nt workgroups that share the 512-byte rows of a q range sit on one XCD (ids 8 apart) next to each other in time
-    const int tr = (id >> 3) % a.nt, qc = (id & 7) + 8 * (id / (8 * a.nt));
+    const int tr = (idl >> 3) % a.nt, qc = (idl & 7) + 8 * (idl / (8 * a.nt));
     const int t0 = 16 * tr;
     const int total = a.Q >> 3;
     const int it_beg = (int)((int64_t)qc * total / a.nqc), it_end = (int)((int64_t)(qc + 1) * total / a.nqc);
 
     for (int e = tid; e < NB * 20; e += 512) {
         const int b = e / 20, c = e - 20 * b;
-        const double v = c < a.ll ? a.C[(int64_t)b * a.ll + c] : 0.0;
+        const double v = c < a.ll ? a.C[((int64_t)bb * NB + b) * a.ll + c] : 0.0;
         if (c < 16) Cf[b * 16 + c] = v; else Cs[b * 4 + c - 16] = v;
     }
 
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     const uint32_t xoff0 = (uint32_t)((xrow * a.T + xcol) * 8), xoff1 = (uint32_t)(((xrow ^ 1) * a.T + xcol) * 8);
     const int pU = 64 * w + lane, prow = (pU / 24) & 7, ppair = pU % 24;
     const uint32_t poff = (uint32_t)((prow * a.r + (2 * ppair + 2 <= a.r ? 2 * ppair : 0)) * 8);
-    const char *xbase = (const char *)a.X + ((int64_t)w * NBW * a.sb + t0) * 8;
+    const char *xbase = (const char *)a.X + (((int64_t)bb * NB + w * NBW) * a.sb + t0) * 8;
     auto issue = [&](int it, int buf) {
         const int64_t tile = uniform_i64((int64_t)it * 8 * a.T * 8);
 #pragma unroll
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     const int64_t zs_row = (int64_t)a.Q * a.T;
     const uint32_t zoff = (uint32_t)((kq * zs_row + x16) * 8);          // 3 Q T doubles at most: the host checks the range
     auto store_z = [&](int it) {
-        const int64_t at = uniform_i64((((int64_t)it * 8 + w) * a.T + t0) * 8);
+        const int64_t at = uniform_i64(((int64_t)bb * a.zblock + ((int64_t)it * 8 + w) * a.T + t0) * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (kq + 4 * j < a.ll) *(double *)((char *)a.Z + uniform_i64(at + 4 * j * zs_row * 8) + zoff) = zp[j];
@@ -221,17 +228,18 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 }
 
 // U[b][p][t] = sum over the q chunks; one thread per accumulator element of a t range
-__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int nt, int nqc, int T, int r, double *U)
+__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int nt, int nqc, int nbb, int T, int r, double *U)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int per = NB * 640;
-    if (e >= (int64_t)per * nt) return;
-    const int tr = (int)(e / per), f = (int)(e - (int64_t)tr * per);
+    if (e >= (int64_t)per * nt * nbb) return;
+    const int bt = (int)(e / per), f = (int)(e - (int64_t)bt * per);
+    const int bb = bt / nt, tr = bt - bb * nt;
     const int b = f / 640, slot = (f - 640 * b) >> 6, l = f & 63;
     double s = 0.0;
     for (int qc = 0; qc < nqc; ++qc) {
-        const int id = (qc & 7) + 8 * (tr + nt * (qc >> 3));
-        s += slab[(int64_t)id * per + f];
+        const int64_t id = (int64_t)bb * nt * nqc + (qc & 7) + 8 * (tr + nt * (qc >> 3));
+        s += slab[id * per + f];
     }
     int p, t;
     if (slot < 8) {                       // 16x16x4: register j of lane l is row (l >> 4) + 4 j, column l & 15
@@ -241,7 +249,21 @@ __global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int
         p = 32 + 4 * (slot - 8) + (l & 3);
         t = 4 * ((l >> 2) & 3) + (l >> 4);
     }
-    if (p < r) U[((int64_t)b * r + p) * T + 16 * tr + t] = s;
+    if (p < r) U[(((int64_t)bb * NB + b) * r + p) * T + 16 * tr + t] = s;
+}
+
+// Z = sum of the blocks' partial Z (first mode beyond 64)
+__global__ __launch_bounds__(256) void dense_pass_zsum(const double2 *part, int nbb, int64_t pairs, double2 *Z)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= pairs) return;
+    double2 s = part[e];
+    for (int k = 1; k < nbb; ++k) {
+        const double2 v = part[(int64_t)k * pairs + e];
+        s.x += v.x;
+        s.y += v.y;
+    }
+    Z[e] = s;
 }
 
 }  // namespace
@@ -255,22 +277,33 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     TTSK_ARG(X && C && P && Z && U, "ttsk_dense_first_pass: NULL operand");
     TTSK_ARG(n0 > 0 && Q > 0 && T > 0 && ll > 0 && r > 0, "ttsk_dense_first_pass: empty extent");
     static const int on = [] { const char *e = getenv("TTSK_DENSE_ONE_PASS"); return e ? atoi(e) : 1; }();
-    if (!on || (n0 != 32 && n0 != 64) || (T & 15) || (Q & 7) || ll > 20 || r > 40 || (r & 1) || Q * T >= (1ll << 27) ||
-        (((uintptr_t)X | (uintptr_t)P) & 15)) {
-        set_error("ttsk_dense_first_pass: shape outside the kernel's cover (first mode 32 or 64, last mode a multiple of 16, "
-                  "middle extent a multiple of 8, left rank <= 20, even right rank <= 40)");
+    if (!on || (n0 != 32 && (n0 & 63)) || n0 > 64 * 64 || (T & 15) || (Q & 7) || ll > 20 || r > 40 || (r & 1) || Q * T >= (1ll << 27) ||
+        (((uintptr_t)X | (uintptr_t)P | (uintptr_t)Z) & 15)) {
+        set_error("ttsk_dense_first_pass: shape outside the kernel's cover (first mode 32 or a multiple of 64, last mode a multiple "
+                  "of 16, middle extent a multiple of 8, left rank <= 20, even right rank <= 40)");
         return TTSK_ERR_UNSUPPORTED;
     }
     TTSK_STREAM(st, stream);
     const int nt = (int)(T / 16);
-    int64_t nqc = 8 * std::max<int64_t>(1, 32 / nt);
+    const int NB = n0 == 32 ? 32 : 64, nbb = (int)(n0 / NB);
+    // q ranges: about 256 workgroups for one block of b, about 1024 over all blocks otherwise (several rounds over the CUs even
+    // out the ranges); a multiple of 8, and not more than there are tiles
+    int64_t nqc = 8 * std::max<int64_t>(1, (nbb == 1 ? 32 : (128 + nbb * nt / 2) / (nbb * nt)) / (nbb == 1 ? nt : 1));
+    static const int nqc_env = [] { const char *e = getenv("TTSK_DP_NQC"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (nqc_env > 0 && nbb > 1) nqc = 8 * cdiv(nqc_env, 8);
     nqc = std::min<int64_t>(nqc, 8 * cdiv(Q / 8, 8));          // at least one tile for most chunks
-    const int NB = (int)n0;
-    const int64_t grid = (int64_t)nt * nqc;
+    const int64_t grid = (int64_t)nbb * nt * nqc;
     double *slab = (double *)scratch(stream, SCRATCH_MISC, (size_t)grid * NB * 640 * 8);
     if (!slab) return TTSK_ERR_HIP;
+    // blocks of b: each block's Z is a partial sum over its 64 values of b
+    const int64_t zblock = ll * Q * T;
+    double *zout = Z;
+    if (nbb > 1) {
+        zout = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nbb * zblock * 8);
+        if (!zout) return TTSK_ERR_HIP;
+    }
     static const int dbg = [] { const char *e = getenv("TTSK_DP_DBG"); return e ? atoi(e) : 0; }();
-    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, Z, slab, nt, (int)nqc, dbg};
+    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, zout, slab, nt, (int)nqc, zblock, dbg};
     const size_t lds = (size_t)(2 * NB * 128 + 2 * DP_PBUF + NB * 20) * 8;
     static bool attr = false;
     if (!attr) {
@@ -284,9 +317,14 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     else
         hipLaunchKernelGGL(dense_pass_kernel<4>, dim3((unsigned)grid), dim3(512), lds, st, a);
     TTSK_LAUNCH_CHECK();
-    const int64_t elems = (int64_t)NB * 640 * nt;
-    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, nt, (int)nqc, (int)T, (int)r, U);
+    const int64_t elems = (int64_t)NB * 640 * nt * nbb;
+    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, nt, (int)nqc, nbb, (int)T, (int)r, U);
     TTSK_LAUNCH_CHECK();
+    if (nbb > 1) {
+        const int64_t pairs = zblock / 2;               // Q T is a multiple of 128
+        hipLaunchKernelGGL(dense_pass_zsum, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, st, (const double2 *)zout, nbb, pairs, (double2 *)Z);
+        TTSK_LAUNCH_CHECK();
+    }
     if (prof_on()) prof_close(st);
     return TTSK_OK;
 }

@@ -11,7 +11,8 @@ so ``Z_mu = A_mu X^{<mu+1>}`` follows from ``Z_{mu-1}`` by contracting one mode 
 reads the tensor, the (rho x n^mu) matrices are never formed -- and
 ``Omega_mu[p, m] = sum_{i,k} D_mu[i, k, p] Psi_mu[i, k, m]`` needs no pass at all.  Right: see
 ``_right_product``.  Z_0 and Psi_0 -- the two products that read X -- come from ONE pass where ``ttsk_dense_first_pass``
-covers the shape (``_first_pass``), from two otherwise; two passes over Z_0 follow (rho/n of X each), no
+covers the shape (``_first_pass``), from two otherwise; Z_1 and Psi_1 read Z_0 (rho/n of X) -- once through the same kernel
+where Z_0 is large, twice otherwise; no
 matrix larger than n^{d-2} x rho exists; same numbers as the reference up to the order of summation
 (tests: golden fixtures at 1e-12, C2 at full size).
 """
@@ -125,39 +126,56 @@ def _right_product(S: DevArray, B) -> DevArray:
     return contract("bq,mq->bm", S, _mat(B))
 
 
-def _first_pass(A, B, X) -> bool:
-    """Z_0 and Psi_0 -- the two products that read the tensor -- from ONE read of it (``ttsk_dense_first_pass``,
-    csrc/dense_pass.hip) when both DRMs are tensor trains and the shape is in the kernel's cover.  Both land in ``_shared``
-    under the keys ``_left_product`` / ``_psi_chained`` look them up by."""
+# beyond mode 0 the fused pair only pays on a large left product (C2: 2.7 GB); TTSK_DENSE_PAIR_MIN_BYTES for A/B runs
+_PAIR_MIN_BYTES = int(os.environ.get("TTSK_DENSE_PAIR_MIN_BYTES", 1 << 28))
+
+
+def _first_pass(A, B, X, mu: int = 0) -> bool:
+    """Z_mu and Psi_mu -- the two products that read the tensor (mu = 0) or the previous left product Z_{mu-1} (mu > 0) --
+    from ONE read of it (``ttsk_dense_first_pass``, csrc/dense_pass.hip) when both DRMs are tensor trains and the shape is in
+    the kernel's cover.  Both land in ``_shared`` under the keys ``_left_product`` / ``_psi_chained`` look them up by."""
     import ctypes
     from .. import _native as nat
-    if not (isinstance(A, ChainedUnfolding) and A.prev is None and isinstance(B, ChainedUnfolding) and B.prev is not None):
+    if not (isinstance(A, ChainedUnfolding) and A.depth == mu and isinstance(B, ChainedUnfolding) and B.prev is not None):
         return False
     if os.environ.get("TTSK_DENSE_ONE_PASS", "1") == "0":
         return False
+    if mu == 0:
+        S, rows = X, int(X.shape[0])
+        if X.ndim < 3 or not X.is_contiguous():
+            return False
+    else:
+        # rows (rho_{mu-1}, n_mu) of the previous left product: the same two sums one level down
+        if ("left", _ident(A.prev), id(X.buf), X.offset, mu - 1) not in _shared:
+            return False
+        S = _left_product(A.prev, X, mu - 1)
+        rows = int(A.core.shape[0]) * int(A.core.shape[1])
+        if S.size * 8 < _PAIR_MIN_BYTES or not S.is_contiguous() or S.size % rows:
+            return False
     # (B's columns meet the tensor's position by position -- _right_product -- so the last chained core's mode size is
     # what splits the columns, whatever the tensor's own last mode is)
-    n0, T = int(X.shape[0]), int(B.core.shape[1])
-    cols = int(np.prod(X.shape[1:], dtype=np.int64))
-    if X.ndim < 3 or not X.is_contiguous() or A.core.shape[1] != n0 or cols % T:
+    T = int(B.core.shape[1])
+    cols = S.size // rows
+    if A.core.shape[0] * A.core.shape[1] != rows or cols % T:
         return False
     Q = cols // T
     ll, rho = int(A.core.shape[2]), int(B.core.shape[0])
-    if n0 not in (32, 64) or T % 16 or Q % 8 or ll > 20 or rho > 40 or rho % 2 or Q * T >= 1 << 27:
+    if (rows != 32 and rows % 64) or T % 16 or Q % 8 or ll > 20 or rho > 40 or rho % 2 or Q * T >= 1 << 27:
         return False
     P = B.prev._rows().contiguous()
     if tuple(P.shape) != (Q, rho):
         return False
-    C = A.core[0].contiguous()
-    Z, U = DevArray.empty((ll, Q * T)), DevArray.empty((n0, rho, T))
+    C = A.core.reshape(rows, ll).contiguous()
+    Z, U = DevArray.empty((ll, Q * T)), DevArray.empty((rows, rho, T))
     V = ctypes.c_void_p
     try:
-        nat.call("ttsk_dense_first_pass", V(X.ptr), n0, Q, T, V(C.ptr), ll, V(P.ptr), rho, V(Z.ptr), V(U.ptr), 0)
+        nat.call("ttsk_dense_first_pass", V(S.ptr), rows, Q, T, V(C.ptr), ll, V(P.ptr), rho, V(Z.ptr), V(U.ptr), 0)
     except nat.TtskUnsupported:
         return False
-    _shared[("left", _ident(A), id(X.buf), X.offset, 0)] = (A, X, Z)
-    Psi0 = contract("bpt,ptm->bm", U, B.core)[None]
-    _shared[("psi", _ident(None), _ident(B), id(X.buf), X.offset, 0)] = (None, B, X, Psi0)
+    _shared[("left", _ident(A), id(X.buf), X.offset, mu)] = (A, X, Z)
+    Psi = contract("bpt,ptm->bm", U, B.core)
+    Psi = Psi[None] if mu == 0 else Psi.reshape(int(A.core.shape[0]), int(A.core.shape[1]), -1)
+    _shared[("psi", _ident(A.prev), _ident(B), id(X.buf), X.offset, mu)] = (A.prev, B, X, Psi)
     return True
 
 
@@ -186,8 +204,8 @@ def sketch_omega_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
     X = tensor.dev_data()
     A, B = _norm(left_sketch), _norm(right_sketch)
     if isinstance(A, ChainedUnfolding) and A.depth == mu:
-        if mu == 0 and ("psi", _ident(None), _ident(B), id(X.buf), X.offset, 0) not in _shared:
-            _first_pass(A, B, X)
+        if ("psi", _ident(A.prev), _ident(B), id(X.buf), X.offset, mu) not in _shared:
+            _first_pass(A, B, X, mu)
         Psi = _psi_chained(A.prev, B, X, mu)
         return contract("ikp,ikm->pm", A.core, Psi)
     A = _mat(A)
