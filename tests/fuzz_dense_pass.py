@@ -1,5 +1,5 @@
 """Randomised shapes for ttsk_dense_first_pass against numpy's einsum (not collected by pytest: run on a GPU box as
-``python tests/fuzz_dense_pass.py [seconds] [seed]``).  Every shape in the kernel's cover: first mode 32 / 64, last mode a
+``python tests/fuzz_dense_pass.py [seconds] [seed]``).  Every shape in the kernel's cover: first mode 32 / 64 / a multiple of 64, last mode a
 multiple of 16, middle extent a multiple of 8 (one tile up to hundreds per q range, ragged ranges), ranks 1..20 / 2..40."""
 import ctypes
 import os
@@ -21,7 +21,7 @@ def main():
     V = ctypes.c_void_p
     t_end, cases, worst = time.time() + seconds, 0, 0.0
     while time.time() < t_end:
-        n0 = int(rng.choice([32, 64]))
+        n0 = int(rng.choice([32, 64, 64, 128, 192, 320]))            # beyond 64: blocks of 64 with partial Z
         T = 16 * int(rng.integers(1, 7))
         Q = 8 * int(rng.integers(1, 41)) if rng.random() < 0.8 else 8 * int(rng.integers(100, 1200))
         ll, r = int(rng.integers(1, 21)), 2 * int(rng.integers(1, 21))
