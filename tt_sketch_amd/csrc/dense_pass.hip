@@ -14,8 +14,9 @@
 // instruction per b: one row of the tensor, one page), two images, and is read twice from there: once with q as the K index of
 // the matrix instruction (U: lanes (t, q)), once with b as the K index (Z: lanes (t, b); wave w takes row q0 + w and chains
 // over all b).  Row q of b's chunk sits at row q ^ (b & 1): both fragment shapes then read 32 consecutive doubles per half
-// wave (SQ_LDS_BANK_CONFLICT = 0).  The next tile's loads are issued behind the first two steps of a tile, so that the matrix
-// pipes start right behind the barrier -- which carries no fence.  The tensor is read once (8.59 GB at C2 instead of 17.2), Z
+// wave (SQ_LDS_BANK_CONFLICT = 0).  The next tile's loads are issued one instruction per step from the second step of a tile on, so
+// that the matrix pipes start right behind the barrier -- which carries no fence -- and no wave's instruction stream waits behind a
+// burst of loads.  The tensor is read once (8.59 GB at C2 instead of 17.2), Z
 // is written once, the partial U of the q ranges are summed by a second launch.
 //
 // The second pair of a sketch -- Z_1 and Psi_1 from Z_0, whose rows are (p', i_1): 1280 at C2 -- is the same two sums one level down:
@@ -26,8 +27,8 @@
 // Work per tile at NB = 64: U 2 x 64 x (2 x 64 + 2 x 16) + Z 8 x 16 x (64 + 16) = 30720 cycles of the matrix pipes per 64 KB
 // = 129 GF per C2 sketch (no padded rows: 20 = 16 + 4, 40 = 32 + 2 x 4), 1.64 ms at the fp64 peak (SQ_VALU_MFMA_BUSY_CYCLES
 // = 4.03e9 over 1024 SIMDs agrees); the HBM side is 8.59 + 2.68 GB = 2.1 ms at the 5.5 TB/s a mixed stream reaches.
-// Measured: 2.9 - 3.1 ms = 0.53 - 0.57 of the matrix peak, 3.6 - 3.9 TB/s; the same instruction stream
-// takes 2.05 ms without its loads and stores, 2.5 with the loads only, 2.1 with the stores only.
+// Measured: 2.58 - 2.66 ms = 0.62 - 0.64 of the matrix peak, 4.2 - 4.4 TB/s; the same instruction stream
+// takes 2.05 ms without its loads and stores.
 #include "common.h"
 #include <type_traits>
 
@@ -58,7 +59,7 @@ struct DensePass {
     double *slab;          // [workgroup][NB][10][64]: the accumulators as the lanes hold them
     int nt, nqc;           // t ranges (T / 16), q chunks (a multiple of 8)
     int64_t zblock;        // first mode beyond 64: blocks of 64 values of b, blockIdx = block * nt * nqc + ...; block k's partial Z at Z + k * zblock
-    int dbg;               // diagnostics (TTSK_DP_DBG): 1 = no tile loads after the first, 2 = no Z stores, 4 = no rotated start
+    int dbg;               // diagnostics (TTSK_DP_DBG): 1 = no tile loads after the first, 2 = no Z stores, 4 = no rotated start, 8 = loads and stores of a tile in one burst
 };
 
 constexpr int DP_PROW = 48;        // doubles per row of the P image (40 used; 48 = 96 dwords: rows kq, kq + 1 on disjoint banks)
@@ -98,20 +99,27 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     const int pU = 64 * w + lane, prow = (pU / 24) & 7, ppair = pU % 24;
     const uint32_t poff = (uint32_t)((prow * a.r + (2 * ppair + 2 <= a.r ? 2 * ppair : 0)) * 8);
     const char *xbase = (const char *)a.X + (((int64_t)bb * NB + w * NBW) * a.sb + t0) * 8;
-    auto issue = [&](int it, int buf) {
-        const int64_t tile = uniform_i64((int64_t)it * 8 * a.T * 8);
-#pragma unroll
-        for (int u = 0; u < NBW; ++u) {
-            const char *src = xbase + uniform_i64(tile + (int64_t)u * a.sb * 8) + ((u & 1) ? xoff1 : xoff0);
-            // (aux = 2: non-temporal -- every byte of the tensor is used exactly once; 3 % on the whole kernel)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(Xl + (buf * NB + w * NBW + u) * 128), 16, 0, 2);
-        }
+    // (one chunk at a time: `issue_x(tile offset, image, u)` is spread over the steps of a tile -- eight load instructions in a
+    // row from each of eight waves stall every wave's instruction stream, and with it the matrix pipes, behind the address unit:
+    // 2.86 -> 2.58 ms at C2)
+    auto issue_x = [&](int64_t tile, int buf, int u) {
+        const char *src = xbase + uniform_i64(tile + (int64_t)u * a.sb * 8) + ((u & 1) ? xoff1 : xoff0);
+        // (aux = 2: non-temporal -- every byte of the tensor is used exactly once; 3 % on the whole kernel)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(Xl + (buf * NB + w * NBW + u) * 128), 16, 0, 2);
+    };
+    auto issue_p = [&](int it, int buf) {
         if (w < 3) {
             const char *src = (const char *)a.P + uniform_i64((int64_t)it * 8 * a.r * 8) + poff;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(Pl + buf * DP_PBUF + w * 128), 16, 0, 0);
         }
+    };
+    auto issue = [&](int it, int buf) {
+        const int64_t tile = uniform_i64((int64_t)it * 8 * a.T * 8);
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) issue_x(tile, buf, u);
+        issue_p(it, buf);
     };
 
     v4d acc[NBW][2];
@@ -163,6 +171,8 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         double zs = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = 0.0;
+        const int next_it = rel + 1 < len ? tile_of(rel + 1) : 0;
+        const int64_t next_tile = uniform_i64((int64_t)next_it * 8 * a.T * 8);
         const double *xu = xb + w * NBW * 128 + x16;
         const double *xz = xb + kq * 128 + (w ^ (kq & 1)) * 16 + x16;
         const double *cf = Cf + kq * 16 + x16, *cs = Cs + kq * 4 + (x16 & 3);
@@ -198,11 +208,19 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 1) {
-                // behind the first steps, so that the matrix pipes start right after the barrier: the next tile's loads (its
-                // image was last read before that barrier) and the previous tile's row of Z
-                if (rel + 1 < len && !(a.dbg & 1)) issue(tile_of(rel + 1), buf ^ 1);
-                if (rel > 0 && !(a.dbg & 2)) store_z(tile_of(rel - 1));
+            // behind the first step, so that the matrix pipes start right after the barrier, and ONE instruction per step: the
+            // next tile's loads (its image was last read before that barrier) at steps 1 .. NBW, the rows of P, then the
+            // previous tile's row of Z.  (TTSK_DP_DBG=8: all of them behind step 1, as one burst.)
+            if ((a.dbg & 8) ? s == 1 : (s >= 1 && s <= NBW + 2)) {
+                const bool more = rel + 1 < len && !(a.dbg & 1);
+                if (a.dbg & 8) {
+                    if (more) issue(tile_of(rel + 1), buf ^ 1);
+                    if (rel > 0 && !(a.dbg & 2)) store_z(tile_of(rel - 1));
+                } else {
+                    if (s <= NBW) { if (more) issue_x(next_tile, buf ^ 1, s - 1); }
+                    else if (s == NBW + 1) { if (more) issue_p(next_it, buf ^ 1); }
+                    else if (rel > 0 && !(a.dbg & 2)) store_z(tile_of(rel - 1));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
