@@ -699,7 +699,7 @@ def bench_c2(args, job):
                 warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f64", data="synthetic",
                 config=dict(workload="C2: general_sketch of a dense fp64 tensor d=5 n=64 (8.59 GB resident), TensorTrainDRM l=20 r=40"),
-                roofline=dict(bound="hbm", kernel="dense_pass_kernel (Z_0 and Psi_0 from one read of X, Z_1 and Psi_1 from one read of Z_0; 92 % of the sketch)",
+                roofline=dict(bound="hbm", kernel="dense_pass_kernel (Z_0 and Psi_0 from one read of X, Z_1 and Psi_1 from one read of Z_0; 90 % of the sketch)",
                               achieved=one_pass / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s",
                               frac=one_pass / t_step / (HBM_TBS * 1e12), traffic=load_traffic("c2_sketch"),
                               what="SURVEY 8d one-pass bytes (8.59 GB tensor + 8.18 GB of DRM matrices) / wall time of one sketch; "
