@@ -52,7 +52,7 @@ def test_first_pass_against_einsum(tsa, n0, Q, T, ll, r):
     assert _rel(U.get(), np.einsum("qp,bqt->bpt", P, X)) < 1e-13
 
 
-@pytest.mark.parametrize("bad", ["n0", "T", "Q", "ll", "r", "odd r"])
+@pytest.mark.parametrize("bad", ["n0", "T", "Q", "ll", "r", "odd r", "partials"])
 def test_first_pass_declines_outside_its_cover(tsa, bad):
     from tt_sketch_amd import _native as nat
     from tt_sketch_amd.device import DevArray
@@ -63,8 +63,12 @@ def test_first_pass_declines_outside_its_cover(tsa, bad):
     if bad == "ll": ll = 21
     if bad == "r": r = 42
     if bad == "odd r": r = 39
-    X, C, P = DevArray.empty((n0, Q, T)), DevArray.empty((n0, ll)), DevArray.empty((Q, r))
-    Z, U = DevArray.empty((ll, Q, T)), DevArray.empty((n0, r, T))
+    if bad == "partials": n0, Q, T = 64 * 40, 8 * 1024, 128       # 40 blocks x 20 x 2^20 doubles of partial Z: 6.7 GB
+    if bad == "partials":          # (declined before anything is touched: no 21 GB operand for this)
+        X = C = P = Z = U = DevArray.empty((64,))
+    else:
+        X, C, P = DevArray.empty((n0, Q, T)), DevArray.empty((n0, ll)), DevArray.empty((Q, r))
+        Z, U = DevArray.empty((ll, Q, T)), DevArray.empty((n0, r, T))
     V = ctypes.c_void_p
     with pytest.raises(nat.TtskUnsupported):
         nat.call("ttsk_dense_first_pass", V(X.ptr), n0, Q, T, V(C.ptr), ll, V(P.ptr), r, V(Z.ptr), V(U.ptr), 0)

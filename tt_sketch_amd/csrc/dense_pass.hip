@@ -311,6 +311,11 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     if (nqc_env > 0 && nbb > 1) nqc = 8 * cdiv(nqc_env, 8);
     nqc = std::min<int64_t>(nqc, 8 * cdiv(Q / 8, 8));          // at least one tile for most chunks
     const int64_t grid = (int64_t)nbb * nt * nqc;
+    // partial results beyond 4 GB (many blocks of a large operand): not this kernel's case -- the caller forms the products separately
+    if ((nbb > 1 && (int64_t)nbb * ll * Q * T * 8 > (4ll << 30)) || grid * NB * 640 * 8 > (4ll << 30)) {
+        set_error("ttsk_dense_first_pass: %d blocks of rows would need more than 4 GB of partial results", nbb);
+        return TTSK_ERR_UNSUPPORTED;
+    }
     double *slab = (double *)scratch(stream, SCRATCH_MISC, (size_t)grid * NB * 640 * 8);
     if (!slab) return TTSK_ERR_HIP;
     // blocks of b: each block's Z is a partial sum over its 64 values of b
