@@ -865,6 +865,8 @@ def run_extras(args, job):
     sub.steps, sub.warmup = 5, 2
     for name, fn in (("c5", bench_c5), ("c4", bench_c4), ("c2", bench_c2)):
         t0 = time.perf_counter()
+        # (c2: a sketch is 4 ms and its first calls grow the library's scratch arenas by 1.3 GB -- a few more of both)
+        sub.steps, sub.warmup = (10, 3) if name == "c2" else (5, 2)
         try:
             extra[name] = compact(fn(sub, job))
             extra[name]["bench_wall_s"] = time.perf_counter() - t0
@@ -872,6 +874,7 @@ def run_extras(args, job):
             extra[name] = dict(error=f"{type(e).__name__}: {e}")
         from tt_sketch_amd.device import release_cached
         release_cached()
+    sub.steps, sub.warmup = 5, 2
     try:
         extra["c3_solves"] = bench_c3_solves(sub, job)
     except Exception as e:
