@@ -17,7 +17,8 @@ from oracle import ttsk_oracle as orc
 pytestmark = pytest.mark.gpu
 
 SHAPE, S_IN, L, R = (200,) * 6, 100, 50, 100
-TENSOR_TOL = 1e-8          # tensor-level bar for cores that went through a pseudo-inverse / QR
+TENSOR_TOL = 1e-10         # tensor-level bar for cores that went through a pseudo-inverse / QR: SURVEY section 8c's bar for full-rank
+                           # Omega (measured since the refinement step of the assembly: 5e-14 median, 4e-11 max)
 ORTH_TOL = 1e-11           # || Q^T Q - I ||_F of every left unfolding
 
 
@@ -131,7 +132,8 @@ def test_c3_rank_deficient_omega(tsa):
     got = [np.asarray(c) for c in stt.to_tt().cores]
     assert tt_rel_diff(got, cores) < 1e-9
     oP, oO = orc.general_sketch("tt", cores, ld, rd, "streaming")
-    assert tt_rel_diff(got, orc.assemble(oP, oO, "right")) < TENSOR_TOL
+    # rank-deficient Omega: both sides truncate at their own noise floor -- the exact-recovery bar, not the full-rank one
+    assert tt_rel_diff(got, orc.assemble(oP, oO, "right")) < 1e-9
     tt = tsa.orthogonal_sketch(X, (L,) * 5, (R,) * 5, left_drm=left, right_drm=right)
     got = [np.asarray(c) for c in tt.cores]
     assert tt_rel_diff(got, cores) < 1e-9

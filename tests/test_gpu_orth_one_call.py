@@ -207,6 +207,30 @@ def test_assemble_one_call_matches_the_pair_by_pair_path(tsa, monkeypatch, direc
 
 
 @pytest.mark.parametrize("direction", ["right", "left"])
+def test_assemble_one_call_d12_mixed_mode_sizes(tsa, monkeypatch, direction):
+    """d = 12 with uniform ranks and two mode sizes: the interior pairs whose mode equals n[1] are grouped into batched
+    launches, the others (among them pairs k >= 9, which share a helper stream with a grouped pair k - 8) run on helper
+    streams that must be forked behind the batched pseudo-inverses whichever pair reaches them first."""
+    from tt_sketch_amd.sketch import assemble_sketched_tt
+    shape = (9, 12, 12, 12, 12, 12, 12, 12, 12, 10, 11, 13)
+    d = len(shape)
+    lr, rr = (5,) * (d - 1), (8,) * (d - 1)
+    if direction == "left":
+        lr, rr = rr, lr
+    rng = np.random.default_rng(33)
+    X = tsa.TensorTrain(orc.random_tt(shape, 3, rng))
+    for rep in range(3):                                  # a race does not show every time
+        stt = tsa.stream_sketch(X, lr, rr, seed=7 + rep)
+        monkeypatch.setenv("TTSK_ASSEMBLE_ONE_CALL", "1")
+        one = [np.asarray(c) for c in assemble_sketched_tt(stt.sketch_ if hasattr(stt, "sketch_") else stt.sketch, direction=direction)]
+        monkeypatch.setenv("TTSK_ASSEMBLE_ONE_CALL", "0")
+        pairs = [np.asarray(c) for c in assemble_sketched_tt(stt.sketch_ if hasattr(stt, "sketch_") else stt.sketch, direction=direction)]
+        for a, b in zip(one, pairs):
+            assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+        assert tsa.TensorTrain(one).error(X) < 1e-8
+
+
+@pytest.mark.parametrize("direction", ["right", "left"])
 def test_assembly_matches_lstsq_for_ill_conditioned_omega(tsa, monkeypatch, direction):
     """Omega with singular values from 1 down to 1e-4 (what the sketches of TT-GMRES iterates look like): the assembled
     tensor agrees with scipy.linalg.lstsq -- the reference's solve, utils.py:98-109 -- to 1e-11 on BOTH assembly paths.

@@ -1304,20 +1304,3 @@ def test_tt_svd_with_an_unfolding_beyond_one_workgroup(tsa):
     for c in tt.cores[:-1]:
         Q = np.asarray(c).reshape(-1, c.shape[2])
         assert np.max(np.abs(Q.T @ Q - np.eye(Q.shape[1]))) < 1e-10
-
-
-def test_power_decay_tensor_and_projector(tsa):
-    """The remaining helpers of the reference's utils.py (:42-60, :112-118): a Gaussian tensor whose unfoldings had
-    their (normalised) singular values multiplied by k^-pow, mode after mode, and the oblique projector."""
-    from tt_sketch_amd import utils
-    X = utils.power_decay_tensor((6, 7, 8), pow=2.0, seed=5)
-    assert X.shape == (6, 7, 8)
-    sv = np.linalg.svd(utils.matricize(X, 2), compute_uv=False)
-    assert np.all(np.diff(sv) < 0) and np.all(sv / sv[0] <= 1.0 / np.arange(1, 9) ** 2.0 * (1 + 1e-12))
-    assert np.array_equal(X, utils.power_decay_tensor((6, 7, 8), pow=2.0, seed=5))
-    rng = np.random.default_rng(3)
-    A, B = rng.standard_normal((30, 6)), rng.standard_normal((30, 6))
-    P = utils.projector(A)
-    assert np.allclose(P @ P, P, atol=1e-12) and np.allclose(P, P.T, atol=1e-12) and np.allclose(P @ A, A, atol=1e-12)
-    Q = utils.projector(A, B)
-    assert np.allclose(Q, A @ np.linalg.pinv(B.T @ A) @ B.T, atol=1e-11) and np.allclose(Q @ Q, Q, atol=1e-10)

@@ -297,3 +297,27 @@ def test_public_names_of_the_reference_are_present():
     for attr in ("left_rank", "right_rank", "Psi_cores", "Omega_mats", "C_cores", "T", "to_tt", "to_numpy", "increase_rank",
                  "error", "dense"):
         assert hasattr(SketchedTensorTrain, attr), attr
+
+
+def test_shard_bounds_cover_everything():
+    from tt_sketch_amd.distributed import shard_bounds
+    for n in (0, 1, 5, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sparse_one_pass_path_declines_a_mode_beyond_its_sort_key():
+    """The mode-order sort key of the one-pass sparse path holds the mode index in 24 bits (ttsk_sparse_mode_order): a
+    longer mode is declined BEFORE anything touches the device, so that the panel path takes over."""
+    from tt_sketch_amd import SparseGaussianDRM, SparseTensor, sparse_fused
+    from tt_sketch_amd.sketch_dispatch import SketchMethod
+    shape = (5, (1 << 24) + 1, 4)
+    idx = np.array([[0, 1], [3, (1 << 24)], [2, 1]])
+    X = SparseTensor(shape, idx, np.array([1.0, -2.0]))
+    left = SparseGaussianDRM((2, 2), shape, transpose=False, seed=1)
+    right = SparseGaussianDRM((3, 3), shape, transpose=True, seed=2)
+    assert sparse_fused.try_sparse_gauss_sketch(X, left, right, SketchMethod.streaming) is None

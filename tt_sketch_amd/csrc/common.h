@@ -14,6 +14,16 @@ int ensure_init();
 // grow-only per-stream arenas; nullptr + error on failure.  Slots keep nested users apart:
 enum { SCRATCH_DRIVER = 0, SCRATCH_GEMM = 1, SCRATCH_MISC = 2, SCRATCH_ORTH = 3, SCRATCH_SLOTS = 4 };
 void *scratch(int stream, int slot, size_t bytes);
+// small allocations that live from first use to ttsk_shutdown (status words, verdict slots), one per key: a re-init on
+// another device gets fresh ones.  nullptr on failure.
+enum { PA_PINV_HOST = 0, PA_PINV_DEV, PA_DEFERRED, PA_PINV_BATCH_VD, PA_DEFERRED_PINNED, PA_SLOTS };
+void *persistent_alloc(int key, size_t bytes, bool host, bool zero);
+// per-function one-time set-up (hipFuncSetAttribute) that has to be repeated after ttsk_shutdown + re-init
+int init_generation();
+struct PerInit {
+    int gen = -1;
+    bool first() { const int g = init_generation(); if (gen == g) return false; gen = g; return true; }
+};
 
 #define TTSK_HIP(call)                                                          \
     do {                                                                        \

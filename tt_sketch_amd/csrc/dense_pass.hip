@@ -328,11 +328,10 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     static const int dbg = [] { const char *e = getenv("TTSK_DP_DBG"); return e ? atoi(e) : 0; }();
     DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, zout, slab, nt, (int)nqc, zblock, dbg};
     const size_t lds = (size_t)(2 * NB * 128 + 2 * DP_PBUF + NB * 20) * 8;
-    static bool attr = false;
-    if (!attr) {
+    static PerInit attr;
+    if (attr.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr = true;
     }
     if (prof_on()) prof_open_named(st, PROF_SOLVE, 0.0, "dense_pass");
     if (NB == 64)

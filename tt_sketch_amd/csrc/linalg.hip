@@ -19,6 +19,9 @@ constexpr int CHOL_MAX_N = 256;
 constexpr int CHOL_SIGN_MAX = 72;             // second factorisation + sign reconstruction in one kernel: three n x (n + 1) images in LDS
 constexpr size_t SMALL_QR_MAX = 19000;      // doubles of LDS the one-workgroup Householder QR may take (152 KB)
 
+// max that keeps a NaN (fmax returns the other operand)
+__device__ __forceinline__ double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
+
 // sum over the 16 lanes of a DPP row, result in every lane: x += ror(x, 8), 4, 2, 1 (v_mov_dpp row_ror)
 template <int CTRL>
 __device__ __forceinline__ double jac_dpp(double v)
@@ -623,17 +626,19 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
         if (core) {
             for (int e = tid; e < n * n; e += 256) {
                 const int i = e / n, c = e - i * n;
-                em = fmax(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
+                em = nan_max(em, fabs(A[i * ld + c] - (i == c ? 1.0 : 0.0)));
             }
-            em = fmax(em, jac_dpp<0xB1>(em));
-            em = fmax(em, jac_dpp<0x4E>(em));
+            em = nan_max(em, jac_dpp<0xB1>(em));
+            em = nan_max(em, jac_dpp<0x4E>(em));
             if ((tid & 3) == 0) shadow[tid >> 2] = em;
         }
         __syncthreads();
         em = 0.0;
-        for (int k = 0; k < 64; ++k) em = fmax(em, shadow[k]);
+        for (int k = 0; k < 64; ++k) em = nan_max(em, shadow[k]);
         __syncthreads();
-        if (em * n <= 1e-8) {                                   // NaN compares false: the recurrence below rejects it
+        // nan_max keeps a NaN (fmax would drop it and a Gram matrix full of NaN would pass as the identity): NaN compares
+        // false here and the recurrence below rejects it
+        if (em * n <= 1e-8) {
             if (core)
                 for (int e = tid; e < n * n; e += 256) {
                     const int i = e / n, c = e - i * n;
@@ -862,11 +867,10 @@ static unsigned chol_threads(int n)
 static int launch_chol(const double *G, int n, double *Rinv, double *Ginv, int *status, double cond_tol, hipStream_t st,
                        int *sticky = nullptr, double *pminmax = nullptr, int count = 1)
 {
-    static bool attr = false;
-    if (!attr) {
+    static PerInit attr;
+    if (attr.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         TTSK_HIP(hipFuncSetAttribute((const void *)hh_sign_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)count), dim3(chol_threads(n)), (size_t)(n * (n + 1) + n) * 8, st, G, n, Rinv, Ginv, status,
                        cond_tol, sticky, pminmax);
@@ -946,22 +950,13 @@ bool fast_solves()
 // verdict into a pinned per-stream slot; `verdict` waits for the stream and reads it.
 static int *pinv_host_status()
 {
-    static int *p = [] {
-        int *q = nullptr;
-        if (hipHostMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int), hipHostMallocDefault) != hipSuccess) q = nullptr;
-        return q;
-    }();
-    return p;
+    return (int *)persistent_alloc(PA_PINV_HOST, TTSK_NUM_STREAMS * sizeof(int), true, false);
 }
 static int g_pinv_began[TTSK_NUM_STREAMS];
 // the verdict of the attempt on the device, outside the scratch arena (which the Jacobi fallback reuses)
 static int *pinv_dev_status(int stream)
 {
-    static int *p = [] {
-        int *q = nullptr;
-        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) q = nullptr;
-        return q;
-    }();
+    int *p = (int *)persistent_alloc(PA_PINV_DEV, TTSK_NUM_STREAMS * sizeof(int), false, false);
     return p ? p + stream : nullptr;
 }
 
@@ -969,12 +964,7 @@ static int *pinv_dev_status(int stream)
 // last ttsk_deferred_status
 int *deferred_flag(int stream)
 {
-    static int *p = [] {
-        int *q = nullptr;
-        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) return (int *)nullptr;
-        if (hipMemset(q, 0, TTSK_NUM_STREAMS * sizeof(int)) != hipSuccess) return (int *)nullptr;
-        return q;
-    }();
+    int *p = (int *)persistent_alloc(PA_DEFERRED, TTSK_NUM_STREAMS * sizeof(int), false, true);
     return p ? p + stream : nullptr;
 }
 
@@ -1062,10 +1052,9 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
     if (n > CHOL_MAX || m < n) return 0;
     if (m < 2 * n64 && (size_t)m * n + n <= SMALL_QR_MAX) {
         // nearly square and small: Householder in one workgroup, no gate to fail
-        static bool attr = false;
-        if (!attr) {
+        static PerInit attr;
+        if (attr.first()) {
             TTSK_HIP(hipFuncSetAttribute((const void *)small_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-            attr = true;
         }
         hipLaunchKernelGGL(small_qr_kernel, dim3(1), dim3(1024), ((size_t)m * n + n) * 8, st, A, (int)m, n);
         TTSK_LAUNCH_CHECK();
@@ -1098,10 +1087,9 @@ int qr_cholesky(double *A, int64_t m, int64_t n64, int stream, hipStream_t st, d
     } else if (n <= CHOL_SIGN_MAX) {
         // second factorisation (G ~ identity), top block of Q and the sign reconstruction in ONE kernel
         static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
-        static bool attr = false;
-        if (!attr) {
+        static PerInit attr;
+        if (attr.first()) {
             TTSK_HIP(hipFuncSetAttribute((const void *)chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            attr = true;
         }
         hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), (size_t)(3 * n * (n + 1) + 2 * n) * 8, st, G, n, R2, (double *)nullptr,
                            status + 1, 0.5, sticky, (double *)nullptr, (const double *)Q1, m == n64 ? 1 : 0, chol_expand);
@@ -1291,10 +1279,9 @@ static int launch_cholqr2_lds(double *M, int64_t m, int n, int *status, double c
     const size_t np = 16 * (size_t)((n + 15) >> 4), mp = 16 * (size_t)((m + 15) >> 4);
     const size_t elems = mp * (np + 2) + np * (np + 1) + np;
     if (elems > CHOLQR2_LDS_MAX) return 0;
-    static bool attr = false;
-    if (!attr) {
+    static PerInit attr;
+    if (attr.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)cholqr2_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr = true;
     }
     const size_t lds = elems * 8;
     hipLaunchKernelGGL(cholqr2_lds_kernel, dim3(1), dim3(1024), lds, st, M, (int)m, n, status, cond_tol, sticky);
@@ -1356,10 +1343,9 @@ int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int row
         TTSK_LAUNCH_CHECK();
         return 1;
     }
-    static bool attr = false;
-    if (!attr) {
+    static PerInit attr;
+    if (attr.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)qr_signs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL(qr_signs_kernel, dim3(1), dim3(chol_threads(n)), (size_t)(n * (n + 1) + n) * 8, st, Qtop, n, square, Sprev, rows_per, Sout);
     TTSK_LAUNCH_CHECK();
@@ -1406,7 +1392,7 @@ using namespace ttsk;
 static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
 {
     static const int off = getenv("TTSK_JACOBI_GLOBAL") ? 1 : 0;
-    static int attr_done = 0;
+    static PerInit attr_done;
     const size_t cap = 160 * 1024 - 256;            // 160 KB per CU minus the kernel's few static bytes
     const size_t w = (size_t)mW * nW * 8, v = (size_t)nW * nW * 8;
     const size_t small = ((size_t)nW + (nW + 1) / 2) * 8;          // sigma^2 and the sort order
@@ -1416,7 +1402,7 @@ static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
         if (small + w + v <= cap) { mode = 2; *bytes = small + w + v; }
         else if (small + w <= cap) { mode = 1; *bytes = small + w; }
     }
-    if (!attr_done) {
+    if (attr_done.first()) {
         if (const char *e = getenv("TTSK_JACOBI_PRECOND")) {
             const int v = atoi(e);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(jac_precond_on), &v, sizeof(int));
@@ -1427,7 +1413,6 @@ static int jacobi_lds_mode(int64_t mW, int64_t nW, size_t *bytes)
             set_error("jacobi: cannot raise the dynamic LDS limit");
             return -1;
         }
-        attr_done = 1;
     }
     return mode;
 }
@@ -1515,11 +1500,8 @@ int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64
     TTSK_STREAM(st, stream);
     TTSK_ARG(count >= 1 && count <= SK_MAXB && dev_omegas && dev_pinvs && l >= 1 && r >= 1, "ttsk_pinv_batch: bad argument");
     const int n = (int)(l < r ? l : r);
-    static int *vd = [] {                              // verdicts outside the scratch arena (the Jacobi kernel works there)
-        int *q = nullptr;
-        if (hipMalloc((void **)&q, TTSK_NUM_STREAMS * SK_MAXB * sizeof(int)) != hipSuccess) q = nullptr;
-        return q;
-    }();
+    // verdicts outside the scratch arena (the Jacobi kernel works there)
+    int *vd = (int *)persistent_alloc(PA_PINV_BATCH_VD, TTSK_NUM_STREAMS * SK_MAXB * sizeof(int), false, false);
     if (!fast_solves() || !vd || n > CHOL_ONE || pinv_rcond(l, r, -1.0) > 1e-4) {
         set_error("ttsk_pinv_batch: (%lld x %lld) is outside the batched fast path", (long long)l, (long long)r);
         return TTSK_ERR_UNSUPPORTED;
@@ -1703,11 +1685,7 @@ int ttsk_deferred_status(int stream, int *host_flag)
     TTSK_ARG(sticky, "ttsk_deferred_status: no device flag");
     // through a pinned word: a copy into the caller's pageable int is staged and blocks for ~40 us before the reset is
     // even queued
-    static int *pinned = [] {
-        int *q = nullptr;
-        if (hipHostMalloc((void **)&q, TTSK_NUM_STREAMS * sizeof(int), hipHostMallocDefault) != hipSuccess) q = nullptr;
-        return q;
-    }();
+    int *pinned = (int *)persistent_alloc(PA_DEFERRED_PINNED, TTSK_NUM_STREAMS * sizeof(int), true, false);
     int *dst = pinned ? pinned + stream : host_flag;
     TTSK_HIP(hipMemcpyAsync(dst, sticky, sizeof(int), hipMemcpyDeviceToHost, st));
     TTSK_HIP(hipMemsetAsync(sticky, 0, sizeof(int), st));

@@ -55,6 +55,28 @@ void *scratch(int s, int slot, size_t bytes)
     return g_scratch[s][slot];
 }
 
+static void *g_pa[PA_SLOTS];
+static bool g_pa_host[PA_SLOTS];
+static int g_generation = 0;
+
+int init_generation() { return g_generation; }
+
+void *persistent_alloc(int key, size_t bytes, bool host, bool zero)
+{
+    if (ensure_init() != TTSK_OK || key < 0 || key >= PA_SLOTS) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pa[key]) return g_pa[key];
+    void *q = nullptr;
+    if ((host ? hipHostMalloc(&q, bytes, hipHostMallocDefault) : hipMalloc(&q, bytes)) != hipSuccess) return nullptr;
+    if (zero) {
+        if (host) memset(q, 0, bytes);
+        else if (hipMemset(q, 0, bytes) != hipSuccess) { (void)hipFree(q); return nullptr; }
+    }
+    g_pa[key] = q;
+    g_pa_host[key] = host;
+    return q;
+}
+
 hipStream_t stream_of(int s)
 {
     if (ensure_init() != TTSK_OK) return nullptr;
@@ -115,6 +137,11 @@ int ttsk_shutdown(void)
             g_scratch_bytes[i][k] = 0;
         }
     }
+    for (int k = 0; k < PA_SLOTS; ++k) {
+        if (g_pa[k]) (void)(g_pa_host[k] ? hipHostFree(g_pa[k]) : hipFree(g_pa[k]));
+        g_pa[k] = nullptr;
+    }
+    ++g_generation;
     g_init = false;
     g_device = -1;
     return TTSK_OK;

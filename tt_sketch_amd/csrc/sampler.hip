@@ -223,10 +223,9 @@ static void launch_sample(const int64_t *idx, const IndexMap &im, size_t N, int 
                           double *out, hipStream_t st)
 {
     if (w <= 32) {
-        static bool attr_done = false;       // 256 x w tile + salts + tail queue: up to 82 KB at w = 32
-        if (!attr_done) {
+        static PerInit attr_done;       // 256 x w tile + salts + tail queue: up to 82 KB at w = 32
+        if (attr_done.first()) {
             (void)hipFuncSetAttribute((const void *)sample_rows_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            attr_done = true;
         }
         size_t blocks = (N + 255) / 256;
         if (blocks > (1u << 16)) blocks = 1u << 16;

@@ -334,12 +334,18 @@ int ttsk_sparse_mode_order(const int64_t *dev_idx, int64_t row_stride, size_t N,
     TTSK_STREAM(st, stream);
     TTSK_ARG(dev_idx && dev_perm && r_m >= 0 && mode_row >= 0 && n >= 1, "ttsk_sparse_mode_order: bad argument");
     TTSK_ARG(N < (1ull << 31), "ttsk_sparse_mode_order: more than 2^31 nonzeros");
+    // the key holds the mode index in its upper 24 bits (sg_key_kernel): a longer mode would leave index bits out of the
+    // sort and the stream out of slice order, which the passes rely on -- refuse it, the panel path takes over
+    if (n > (1ll << 24)) {
+        set_error("ttsk_sparse_mode_order: mode of %lld entries, the sort key holds 2^24", (long long)n);
+        return TTSK_ERR_UNSUPPORTED;
+    }
     if (N == 0) return TTSK_OK;
     IndexMap rm{};
     int rc;
     if (r_m && (rc = make_index_map(r_shape, r_m, row_stride, r_rows, &rm))) return rc;
     int bits = 1;
-    while ((1ll << bits) < n && bits < 23) ++bits;
+    while ((1ll << bits) < n && bits < 24) ++bits;
     size_t temp_bytes = 0;
     TTSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                                 (const int64_t *)nullptr, (int64_t *)nullptr, (int)N, 0, 40 + bits, st));
@@ -428,10 +434,9 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     a.part_j = (int *)(a.part_om + wtot * (size_t)cellsO);
     const size_t per_wave = (size_t)SG_T * a.tcols + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * a.qcols + 3) / 4;
     const size_t lds = per_wave * 4 * 8;
-    static bool attr = false;
-    if (!attr) {
+    static PerInit attr;
+    if (attr.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr = true;
     }
     const bool prof = prof_on();
     if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");

@@ -8,10 +8,9 @@ template <int NF, int STR, int UNR>
 static int launch_ss_one(const StreamSmall &a, size_t lds, int grid, hipStream_t st)
 {
     auto kern = stream_small_kernel<NF, STR, 5, UNR>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerInit attr_done;
+    if (attr_done.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
     TTSK_LAUNCH_CHECK();
@@ -97,10 +96,9 @@ template <int NF, int STR, int UNR>
 static int launch_sss_one(const StreamSmallSum &a, size_t lds, int grid, hipStream_t st)
 {
     auto kern = stream_small_sum_kernel<NF, STR, 5, UNR>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerInit attr_done;
+    if (attr_done.first()) {
         TTSK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
     TTSK_LAUNCH_CHECK();

@@ -213,7 +213,6 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
              "ttsk_tt_assemble: bad argument");
     int rc;
 #define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
-    const int nstreams = std::min(d - 1, TTSK_NUM_STREAMS);
     // Omega of one shape: the pseudo-inverses as batched launches on `stream`, then only the products are dealt out
     bool batched = d - 1 >= 2 && d - 1 <= SK_MAXB;
     for (int k = 0; k < d - 1; ++k) {
@@ -274,10 +273,14 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
             }
         }
     }
+    // A helper stream is forked the first time a pair actually lands on it (grouped pairs never touch theirs, so "k below
+    // the stream count" is not that moment: with d - 1 >= 10 an ungrouped pair k >= 9 could meet a stream whose earlier pair
+    // k - 8 had been grouped and that was therefore never forked) and exactly the forked ones are joined at the end.
+    bool forked[TTSK_NUM_STREAMS] = {};
     for (int k = 0; k < d - 1; ++k) {
         if (grouped[k]) continue;
         const int q = (stream + k) % TTSK_NUM_STREAMS;
-        if (k < nstreams && q != stream) CK(ttsk_stream_wait(q, stream));        // fork
+        if (q != stream && !forked[q]) { CK(ttsk_stream_wait(q, stream)); forked[q] = true; }     // fork
         if (!batched) {
             CK(ttsk_pinv_begin(omega[k], lr[k], rr[k], -1.0, work[k], q));
             CK(ttsk_pinv_end(omega[k], lr[k], rr[k], -1.0, work[k], nullptr, q));
@@ -320,10 +323,8 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
     TTSK_ARG(psi[e] && cores_out[e], "ttsk_tt_assemble: NULL core %d", e);
     const int64_t sz = direction == 0 ? lr[d - 2] * n[d - 1] : n[0] * rr[0];
     if (cores_out[e] != psi[e]) TTSK_HIP(hipMemcpyAsync(cores_out[e], psi[e], (size_t)sz * 8, hipMemcpyDeviceToDevice, st));
-    for (int k = 0; k < nstreams; ++k) {
-        const int q = (stream + k) % TTSK_NUM_STREAMS;
-        if (q != stream) CK(ttsk_stream_wait(stream, q));                         // join
-    }
+    for (int q = 0; q < TTSK_NUM_STREAMS; ++q)
+        if (forked[q]) CK(ttsk_stream_wait(stream, q));                           // join
 #undef CK
     return TTSK_OK;
 }

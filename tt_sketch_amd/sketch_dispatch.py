@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import enum
 from functools import partial
 from typing import Callable, List, Optional, Tuple
@@ -195,6 +196,9 @@ def general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DR
 
 
 _ONE_CALL_ORTH = os.environ.get("TTSK_ORTH_ONE_CALL", "1") != "0"
+# how often an orthogonal / hmt sketch had to be repeated on the robust factorisations (per method): systematically
+# ill-conditioned inputs pay for the sketch twice, and this is where that shows
+robust_reruns: dict = {}
 
 
 def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM,
@@ -204,16 +208,28 @@ def _general_sketch_device(tensor: Tensor, left_drm: Optional[DRM], right_drm: D
         # d - 1 steps are sequential in mu: each blocking read-back drains the queue).  ONE read-back at the end; a
         # rejected factorisation (rank-deficient Omega, ill-conditioned unfolding) repeats the sketch on the robust path.
         from . import tt_fused
-        out = tt_fused.try_orth_sketch(tensor, left_drm, right_drm, method) if _ONE_CALL_ORTH else None
-        if out is None:
+        out, flag = None, ctypes.c_int(0)
+        try:
+            out = tt_fused.try_orth_sketch(tensor, left_drm, right_drm, method) if _ONE_CALL_ORTH else None
+            if out is None:
+                try:
+                    out = _sketch_pass(tensor, left_drm, right_drm, method, deferred=True)
+                except nat.TtskUnsupported:
+                    out = None
+        finally:
+            # read AND clear the sticky flag whatever the pass raised (a ValueError of the argument checks, a HIP error):
+            # left set, it would send the next, unrelated sketch to the robust path
             try:
-                out = _sketch_pass(tensor, left_drm, right_drm, method, deferred=True)
-            except nat.TtskUnsupported:
-                out = None
-        flag = ctypes.c_int(0)
-        nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+                nat.call("ttsk_deferred_status", 0, ctypes.byref(flag))
+            except nat.TtskError:
+                if out is not None:          # (otherwise the pass's own exception is the one to report)
+                    raise
         if out is not None and not flag.value:
             return out
+        robust_reruns[method.value] = robust_reruns.get(method.value, 0) + 1
+        if os.environ.get("TTSK_TRACE_RERUN", "0") != "0":
+            print(f"tt_sketch_amd: {method.value} sketch repeated on the robust factorisations "
+                  f"(optimistic pass {'rejected' if out is not None else 'unsupported'})", file=sys.stderr)
     return _sketch_pass(tensor, left_drm, right_drm, method, deferred=False)
 
 

@@ -22,6 +22,7 @@ from .tensor import SparseTensor
 
 last_plan: dict = {}             # what the last sketch did (bench.py reads it): sampled columns per nonzero, table rows
 MAX_WIDTH = 16                   # columns per DRM factor the pass kernel holds in one matrix tile
+MAX_MODE = 1 << 24               # the mode-order sort key holds the mode index in 24 bits (ttsk_sparse_mode_order)
 TABLE_BYTES = 32 << 20           # a per-prefix table larger than this is sampled per nonzero instead (it would leave the L2 / MALL)
 
 
@@ -121,6 +122,8 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
     shape = tuple(int(n) for n in tensor.shape)
     d, N = len(shape), tensor.nnz
     if d < 2 or N == 0 or N >= 2**31:
+        return None
+    if max(shape) > MAX_MODE:
         return None
     if tuple(left_drm.shape) != shape or tuple(right_drm.shape) != shape:
         raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensor.shape}")
