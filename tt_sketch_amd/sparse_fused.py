@@ -16,9 +16,9 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _native as nat
-from .device import DevArray
+from .device import DevArray, axpby
 from .drm.sparse_gaussian_drm import SparseGaussianDRM
-from .tensor import SparseTensor
+from .tensor import SparseTensor, TensorSum
 
 last_plan: dict = {}             # what the last sketch did (bench.py reads it): sampled columns per nonzero, table rows
 MAX_WIDTH = 16                   # columns per DRM factor the pass kernel holds in one matrix tile
@@ -115,7 +115,21 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
     from .sketch_dispatch import SketchMethod
     if method != SketchMethod.streaming or os.environ.get("TTSK_SPARSE_FUSED", "1") == "0":
         return None
-    if type(tensor) is not SparseTensor or type(left_drm) is not SparseGaussianDRM or type(right_drm) is not SparseGaussianDRM:
+    if type(left_drm) is not SparseGaussianDRM or type(right_drm) is not SparseGaussianDRM:
+        return None
+    if type(tensor) is TensorSum and tensor.tensors and all(type(t) is SparseTensor for t in tensor.tensors):
+        # a sum of sparse tensors (the nnz shards of distributed.shard_tensor, reference tensor.py:215-234): every summand
+        # through the passes, summed in the order of the summands -- as the reference's += (sketch_dispatch.py:85-139)
+        # and, like the passes themselves, the same bits in every run
+        parts = [try_sparse_gauss_sketch(t, left_drm, right_drm, method) for t in tensor.tensors if t.nnz]
+        if not parts or any(p is None for p in parts):
+            return None
+        Psi, Omega = parts[0]
+        for P2, O2 in parts[1:]:
+            for y, x in zip(Psi + Omega, P2 + O2):
+                axpby(y, x)
+        return Psi, Omega
+    if type(tensor) is not SparseTensor:
         return None
     if left_drm.transpose or not right_drm.transpose:
         return None
