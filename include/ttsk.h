@@ -152,6 +152,16 @@ int ttsk_chain_step(int nb, int n, int K1, int A, int A2, int J, const double *c
 int ttsk_chain_step_wide(int nb, int n, int K1, int A, int A2, int J, const double *const *W, int64_t w_c,
                          const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
                          const double *E, double *const *T, double *const *Out, int stream);
+/* The same step for MANY low-rank tensor trains at once (csrc/chain_sum.h: the summands of a TensorSum,
+ * sketch_dispatch.py:85-147, whose chains share the DRM; K1, J <= 20, A, A2 <= 128, A2 even): the rows of several
+ * terms are stacked into full 16-row tiles, the work of the second product is dealt over the waves by (row tile,
+ * column tile) rectangles.  T (optional) receives the intermediate as T[b * t_b + (a * n + k) * t_ld + j] (t_extent
+ * elements addressable): t_b = J, t_ld = nb * J is the operand layout of the Psi of a sum (one product over (term,
+ * rank)).  TTSK_ERR_UNSUPPORTED outside the cover; ttsk_tt_sketch_sum / _batch then use the other forms. */
+int ttsk_chain_step_sum(int nb, int n, int K1, int A, int A2, int J, const double *const *W, int64_t w_c,
+                        const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
+                        const double *E, double *T, int64_t t_b, int64_t t_ld, int64_t t_extent,
+                        double *const *Out, int stream);
 /* number of doubles ttsk_tt_sketch writes to `out` */
 int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
                             const int64_t *r_lo, const int64_t *r_hi);

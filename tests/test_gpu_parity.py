@@ -1161,6 +1161,66 @@ def test_wide_chain_step_against_einsum(tsa, case):
     _chain_step_case("ttsk_chain_step_wide", case)
 
 
+def _chain_sum_case(case, seed_salt=0):
+    """ttsk_chain_step_sum against the two einsums of tensor_train_drm.py:81-87, T in either layout"""
+    import ctypes
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, sync
+    nb, n, K1, A, A2, J, right, wt = case          # wt: 0 = no T, 1 = interleaved over the terms, 2 = per term
+    rng = np.random.default_rng((hash(case) + seed_salt) % 2**32)
+    W = [rng.standard_normal((K1, A)) for _ in range(nb)]
+    E = rng.standard_normal((A, n, A2))
+    if right:      # X[j][k][c]
+        X = [rng.standard_normal((J, n, K1)) for _ in range(nb)]
+        strides = (n * K1, K1, 1)
+        want_T = [np.einsum("ca,jkc->akj", w, x) for w, x in zip(W, X)]
+    else:          # X[c][k][j]
+        X = [rng.standard_normal((K1, n, J)) for _ in range(nb)]
+        strides = (1, J, n * J)
+        want_T = [np.einsum("ca,ckj->akj", w, x) for w, x in zip(W, X)]
+    want = [np.einsum("akj,akb->jb", t, E) for t in want_T]
+    dW, dX = [DevArray.from_host(w) for w in W], [DevArray.from_host(x) for x in X]
+    dE = DevArray.from_host(E)
+    dO = [DevArray.zeros((J, A2)) for _ in range(nb)]
+    P = ctypes.c_void_p
+    arr = lambda xs: (P * nb)(*[x.ptr for x in xs])
+    dT, t_b, t_ld = None, 0, 0
+    if wt == 1:
+        dT, t_b, t_ld = DevArray.zeros((A, n, nb, J)), J, nb * J
+    elif wt == 2:
+        dT, t_b, t_ld = DevArray.zeros((nb, A, n, J)), A * n * J, J
+    nat.call("ttsk_chain_step_sum", nb, n, K1, A, A2, J, arr(dW), A, arr(dX), strides[0], strides[1], strides[2],
+             X[0].size, P(dE.ptr), None if dT is None else P(dT.ptr), t_b, t_ld, 0 if dT is None else dT.size, arr(dO), 0)
+    sync()
+    for b in range(nb):
+        assert rel(dO[b].get(), want[b]) < TOL, (b, rel(dO[b].get(), want[b]))
+        if wt:
+            got = dT.get()[:, :, b, :] if wt == 1 else dT.get()[b]
+            assert rel(got, want_T[b]) < TOL, (b, rel(got, want_T[b]))
+
+
+@pytest.mark.parametrize("case", [
+    # (nb, n, K1, A, A2, J, right-chain strides?, T: 0 none / 1 interleaved over the terms / 2 per term)
+    (32, 128, 20, 100, 100, 20, True, 0),            # C5 right chain: 8 groups of 4 terms x 32 slice ranges
+    (32, 128, 20, 50, 50, 20, False, 1),             # C5 left chain, T in the layout the Psi of a sum reads
+    (8, 24, 20, 100, 100, 20, True, 0),
+    (8, 24, 20, 50, 50, 20, False, 2),               # T per term (a batch of separate sketches)
+    (7, 19, 20, 100, 100, 20, True, 0),              # terms do not fill the last group
+    (5, 13, 17, 100, 100, 19, True, 1),              # J, K1 not multiples of 4: zero-padded strips
+    (6, 10, 20, 64, 48, 20, False, 1),               # no strip column
+    (9, 11, 12, 30, 22, 9, False, 2),                # small ranks: more terms per workgroup
+    (4, 7, 8, 16, 8, 4, True, 0),                    # output of two strips only
+    (12, 40, 20, 112, 112, 20, True, 0),             # large ranks: two terms per workgroup
+    (16, 33, 20, 100, 56, 16, True, 1),              # A != A2, two strips behind three tiles
+    (4, 1, 20, 100, 100, 20, True, 0),               # one slice
+])
+def test_chain_step_sum_against_einsum(tsa, case):
+    """ttsk_chain_step_sum (csrc/chain_sum.h): rows of several low-rank terms stacked into 16-row tiles that straddle term
+    boundaries in the second product, the first product per term as 4-row strips == the two einsums of
+    tensor_train_drm.py:81-87 per term, and the optional T in both layouts."""
+    _chain_sum_case(case)
+
+
 def test_wide_and_first_fused_kernel_on_shared_shapes(tsa):
     """Where both kernels apply they sum in different orders (chunks); results agree to rounding."""
     for case in [(4, 50, 100, 100, 100, 100, True, False), (2, 40, 64, 52, 50, 33, False, True)]:

@@ -64,6 +64,8 @@ def _bind(lib):
                             POINTER(P), POINTER(P), I],
         "ttsk_chain_step_wide": [I, I, I, I, I, I, POINTER(P), c_int64, POINTER(P), c_int64, c_int64, c_int64, c_int64, P,
                                  POINTER(P), POINTER(P), I],
+        "ttsk_chain_step_sum": [I, I, I, I, I, I, POINTER(P), c_int64, POINTER(P), c_int64, c_int64, c_int64, c_int64, P,
+                                P, c_int64, c_int64, c_int64, POINTER(P), I],
         "ttsk_prof_enable": [I],
         "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],

@@ -6,6 +6,7 @@
 #include "skinny.h"
 #include "chain_fused.h"
 #include "chain_wide.h"
+#include "chain_sum.h"
 #include "tt_chain.h"
 #include "stream_small.h"
 
@@ -297,10 +298,12 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     // sum mode, larger TT ranks: Psi_mu per tensor (the streamed kernel), then one sum -- faster than the generic
     // tiles on a contracted index of nb * s (measured: s = 60, 100); one block per stream of the Psi phase
     static const int sum_psi_split = [] { const char *e = getenv("TTSK_SUM_PSI_SPLIT"); return e ? atoi(e) : 48; }();
+    // (small TT ranks: the same blocks take the partial Psi of the K chunks of the one product over (tensor, rank), below)
+    static const int sum_psi_chunks = [] { const char *e = getenv("TTSK_SUM_PSI_CHUNKS"); return e ? atoi(e) : 1; }();
     size_t szPs = 0;
     if (sum)
         for (int mu = 1; mu < d - 1; ++mu)
-            if (s[mu + 1] > sum_psi_split) {
+            if (s[mu + 1] > sum_psi_split || sum_psi_chunks) {
                 const size_t v = even((size_t)(l_hi[mu - 1] - l_lo[mu - 1]) * n[mu] * (r_hi[d - 2 - mu] - r_lo[d - 2 - mu]));
                 szPs = v > szPs ? v : szPs;
             }
@@ -342,6 +345,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                              DR[j], nullptr, Op};
             g_cls = 1;
             int fz = (sp <= 128 && sn <= 128 && rho <= 128 && rhop <= 128) ? chain_fused_try(cs, stream, st) : 0;
+            // many low-rank tensors (the terms of a sum): rows of several terms stacked into full tiles (chain_sum.h)
+            if (fz == 0) fz = chain_sum_try(ChainSumArgs{cs, nullptr, 0, 0, 0}, stream, st);
             if (fz == 0) fz = chain_wide_try(cs, stream, st);
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
@@ -402,6 +407,20 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                              sn * nn * sp, DL[mu], co ? nullptr : Tp, Op};
             g_cls = 3;
             int fz = (sp <= 128 && sn <= 128 && lfull <= 128 && lt[mu + 1] <= 128) ? chain_fused_try(cs, aux, st_aux) : 0;
+            if (fz == 0) {
+                // stacked-terms kernel: T goes out interleaved over the terms for the Psi of a sum (one product over (term,
+                // rank)), per term otherwise
+                const bool inter = sum && merge_on && nb > 1 && packedL(mu);
+                ChainSumArgs ca{cs, nullptr, 0, 0, 0};
+                if (!co) {
+                    ca.Tint = inter ? ws0 + offT[mu] : Tp0(0, mu);
+                    ca.t_b = inter ? sp : (int64_t)szT[mu];
+                    ca.t_ld = inter ? (int64_t)nb * sp : sp;
+                    ca.t_extent = (int64_t)nb * (int64_t)szT[mu];
+                }
+                fz = chain_sum_try(ca, aux, st_aux);
+                if (fz == 1 && inter) t_inter[mu] = 1;
+            }
             if (fz == 0) fz = chain_wide_try(cs, aux, st_aux);
             g_cls = NCLS - 1;
             if (fz < 0) return fz;
@@ -506,7 +525,36 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             } else if (mu < d - 1 && sum) {
                 // Psi[(q,k), c] = sum_{b, p'} T_b[(q,k), p'] R_b[p', c]: (b, p') is one contracted index when both
                 // operands hold the tensors behind one another, a two-level one otherwise
-                if (t_inter[mu] && packedR(jr))
+                bool chunked = false;
+                if (t_inter[mu] && packedR(jr) && sum_psi_chunks && l * nn >= 1024 && l * nn < (1ll << 30)) {
+                    // K = nb * sp (640 at C5) in chunks whose R image fits the LDS of the streamed kernel (stream_small.h:
+                    // fragments of T straight from memory, R in LDS, no barrier after staging): the chunks are the
+                    // "problems" of one launch, their partial Psi meet in one sum.  (One product on the generic tiles: 52 us
+                    // per mode at C5.)
+                    const int64_t K = (int64_t)nb * sp;
+                    int nch = 0;
+                    for (int t = 1; t <= nb && t <= SK_MAXB && !nch; ++t)
+                        if (K % t == 0 && (K / t) % 4 == 0 && 4 * (K / t / 4 + 6) * ((r + 3) / 4 * 4) * 8 <= 150 * 1024) nch = t;
+                    if (nch >= 1) {
+                        const int64_t Kc = K / nch;
+                        double *blk0 = ws0 + offPs + (size_t)(mu & 1) * blk(nb * szPs);
+                        for (int cidx = 0; cidx < nch; ++cidx) {
+                            p.A[cidx] = Tm(0) + (size_t)cidx * Kc; p.B[cidx] = Rm(0) + (size_t)cidx * Kc * ldr;
+                            p.C[cidx] = nch == 1 ? out + psi_at[mu] : blk0 + (size_t)cidx * szPs;
+                        }
+                        StreamSmallArgs ss{nch, (int)(l * nn), (int)Kc, (int)r, p.A, ldt, p.B, ldr, p.C, r, nch == 1 ? accumulate : 0};
+                        g_cls = 4;
+                        const int fz = stream_small_try(ss, q, stq);
+                        g_cls = NCLS - 1;
+                        if (fz < 0) return fz;
+                        if (fz == 1) {
+                            chunked = true;
+                            if (nch > 1) CK(ttsk_sum_slices(out + psi_at[mu], blk0, nch, szPs, (size_t)(l * nn * r), accumulate, q));
+                        }
+                    }
+                }
+                if (chunked) rc = 0;
+                else if (t_inter[mu] && packedR(jr))
                     rc = gemm(4, l * nn, r, 1, (int64_t)nb * sp, Tm(0), ldt, 0, 1, Rm(0), 0, ldr, 1, out + psi_at[mu], r, 1,
                               accumulate, q);
                 else
@@ -638,8 +686,28 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             CK(psi_omega(d - 1, stream, true, false));
         }
     }
-    if (!grouped)
-        for (int mu = 0; mu < d; ++mu) CK(psi_omega(mu, (mu & 1) ? aux : stream));
+    if (!grouped) {
+        // sum of tensors, all modes of one shape: the d - 1 Omega_mu = sum_{(b,p)} L_all[(b,p), q] R_all[(b,p), c] as ONE
+        // batched small launch (they were 5 launches of 15 us at C5, K = 640 each)
+        bool om_batched = false;
+        if (sum && d - 1 <= SK_MAXB && d >= 3) {
+            bool same = true;
+            for (int mu = 0; mu < d - 1 && same; ++mu)
+                same = s[mu + 1] == s[1] && lt[mu + 1] == lt[1] && rt[d - 1 - mu] == rt[d - 1] && packedL(mu) && packedR(d - 2 - mu) &&
+                       l_hi[mu] - l_lo[mu] == l_hi[0] - l_lo[0] && r_hi[d - 2 - mu] - r_lo[d - 2 - mu] == r_hi[d - 2] - r_lo[d - 2];
+            if (same) {
+                BatchPtrs o{};
+                for (int mu = 0; mu < d - 1; ++mu) {
+                    const int jr = d - 2 - mu;
+                    o.A[mu] = Lp(0, mu) + l_lo[mu]; o.B[mu] = Rp(0, jr) + r_lo[jr]; o.C[mu] = out + om_at[mu];
+                }
+                const int64_t l = l_hi[0] - l_lo[0], r = r_hi[d - 2] - r_lo[d - 2];
+                CK(gemm_batch(5, d - 1, desc2(l, r, 1, (int64_t)nb * s[1], 1, 0, lt[1], 0, rt[d - 1], 1, r, 1, accumulate), o, aux, st_aux));
+                om_batched = true;
+            }
+        }
+        for (int mu = 0; mu < d; ++mu) CK(psi_omega(mu, (mu & 1) ? aux : stream, true, !om_batched));
+    }
     CK(ttsk_stream_wait(stream, aux));   // join
     return TTSK_OK;
 #undef CK
