@@ -71,7 +71,7 @@ def load_traffic(kernel_name):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r02_traffic.json,
     written by profiles/collect_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     streaming reads on gfx950, plus WRITE_SIZE)."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -658,15 +658,17 @@ def bench_c5(args, job):
 
 
 # --------------------------------------------------------------------------- C2: dense d=5 n=64
-def bench_c2(args, job):
+def bench_c2(args, job, gaussian=False):
+    """C2, TensorTrainDRM variant (default) or DenseGaussianDRM variant (device-sampled matrices, SURVEY 8d names both)."""
     nat = job.nat
     import tt_sketch_amd as tsa
     from tt_sketch_amd.utils import random_normal_dev
     shape, l, r = (64,) * 5, 20, 40
     X = random_normal_dev(shape, seed=2)
     T = tsa.DenseTensor(X)
-    left = tsa.TensorTrainDRM(l, shape, False, seed=1)
-    right = tsa.TensorTrainDRM(r, shape, True, seed=2)
+    cls = tsa.DenseGaussianDRM if gaussian else tsa.TensorTrainDRM
+    left = cls(l, shape, False, seed=1)
+    right = cls(r, shape, True, seed=2)
 
     def step():
         tsa.general_sketch(T, left, right, tsa.SketchMethod.streaming)
@@ -674,7 +676,7 @@ def bench_c2(args, job):
     if job.rank != 0:
         return None
     t_step = elapsed / args.steps
-    one_pass, unfused, gflop = 16.77e9, 77.3e9, 484.0
+    x_bytes, mats_bytes, unfused, gflop_ref = 8.59e9, 8.18e9, 77.3e9, 484.0
     cpu = None
     if not args.no_cpu and job.world == 1:
         # the oracle's dense path at full size needs c_einsum over 8.6 GB (minutes): the largest size that
@@ -685,28 +687,59 @@ def bench_c2(args, job):
         rng = np.random.default_rng(2)
         shp = (32,) * 5
         Xs = rng.standard_normal(shp)
-        ld, rd = orc.random_tt_drm(shp, l, False, rng), orc.random_tt_drm(shp, r, True, rng)
+        if gaussian:
+            ld = orc.DenseDrm([rng.standard_normal((l, 32 ** (mu + 1))) for mu in range(4)], shp, False)
+            rd = orc.DenseDrm([rng.standard_normal((r, 32 ** (mu + 1))) for mu in range(4)], shp, True)
+        else:
+            ld, rd = orc.random_tt_drm(shp, l, False, rng), orc.random_tt_drm(shp, r, True, rng)
         with blas_threads():
             t0 = time.perf_counter()
             orc.general_sketch("dense", Xs, ld, rd, "streaming")
             t_cpu = time.perf_counter() - t0
         cpu = dict(value=5 / t_cpu, unit="TT-cores/s", cores=cpu_cores_used(), kind="port", t_sketch_ms=t_cpu * 1e3,
                    gb_per_s=Xs.nbytes / t_cpu * 1e-9,
-                   sample="oracle general_sketch of a dense d=5 n=32 tensor (268 MB = 1/32 of C2), TensorTrainDRM l=20 r=40, "
+                   sample=f"oracle general_sketch of a dense d=5 n=32 tensor (268 MB = 1/32 of C2), {'DenseGaussianDRM' if gaussian else 'TensorTrainDRM'} l=20 r=40, "
                           f"DRMs pre-built, one run (~1 s); {CPU_THREADS} BLAS threads")
         del Xs
-    return dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
+    base = dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype="f64", data="synthetic",
-                config=dict(workload="C2: general_sketch of a dense fp64 tensor d=5 n=64 (8.59 GB resident), TensorTrainDRM l=20 r=40"),
-                roofline=dict(bound="hbm", kernel="dense_pass_kernel (Z_0 and Psi_0 from one read of X, Z_1 and Psi_1 from one read of Z_0; 90 % of the sketch)",
-                              achieved=one_pass / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s",
-                              frac=one_pass / t_step / (HBM_TBS * 1e12), traffic=load_traffic("c2_sketch"),
-                              what="SURVEY 8d one-pass bytes (8.59 GB tensor + 8.18 GB of DRM matrices) / wall time of one sketch; "
-                                   "the sketch itself reads X ONCE (ttsk_dense_first_pass), writes the first left product (2.7 GB) and reads it ONCE "
-                                   "(the same kernel one level down), and forms no DRM matrix beyond 84 MB (dense_sketch.py)",
-                              unfused_77GB_rate_gbs=unfused / t_step * 1e-9, algorithmic_tflops=gflop / t_step * 1e-3),
-                cpu_baseline=cpu)
+                dtype="f64", data="synthetic", cpu_baseline=cpu)
+    if gaussian:
+        # materialised Gaussian matrices: the binding roof is HBM -- SURVEY 8d's one-pass bytes are the tensor once plus
+        # every DRM matrix once
+        alg = x_bytes + mats_bytes
+        traffic = load_traffic("c2_gaussian_sketch")
+        base.update(config=dict(workload="C2 (DenseGaussianDRM): general_sketch of a dense fp64 tensor d=5 n=64 (8.59 GB resident), device-sampled DenseGaussianDRM l=20 r=40 "
+                                         "(8.18 GB of matrices)"),
+                    roofline=dict(bound="hbm", kernel="dense_gauss_pass_kernel (every left product A_mu X^{<mu+1>} and Psi_0 from ONE read of X; the right-hand products read the small left products)",
+                                  achieved=alg / t_step * 1e-9, peak=HBM_TBS * 1e3, unit="GB/s", frac=alg / t_step / (HBM_TBS * 1e12),
+                                  traffic=traffic, traffic_over_algorithmic=None if traffic is None else traffic / alg,
+                                  algorithmic_bytes=alg,
+                                  what="SURVEY 8d one-pass bytes (8.59 GB tensor + 8.18 GB of DRM matrices) / wall time of one sketch",
+                                  mfma_frac_of_algorithmic_flops=gflop_ref / t_step * 1e-3 / PEAK_F64_MFMA_TF,
+                                  algorithmic_tflops=gflop_ref / t_step * 1e-3))
+        return base
+    # TensorTrainDRM recipes: no DRM matrix beyond 84 MB exists, so the bytes that must move are the tensor once (+ the sketch
+    # itself, < 1 MB); the kernels execute 129 GF (pass over X) + 41 GF (pass over the first left product) of the 484 GF the
+    # reference's formulation counts, and the matrix pipe -- not HBM -- is the roof that binds
+    alg = x_bytes
+    executed_gf = 170.0
+    traffic = load_traffic("c2_sketch")
+    hbm_frac = alg / t_step / (HBM_TBS * 1e12)
+    mfma_frac = executed_gf / t_step * 1e-3 / PEAK_F64_MFMA_TF
+    base.update(config=dict(workload="C2: general_sketch of a dense fp64 tensor d=5 n=64 (8.59 GB resident), TensorTrainDRM l=20 r=40"),
+                roofline=dict(bound="mfma", kernel="dense_pass_kernel (Z_0 and Psi_0 from one read of X, Z_1 and Psi_1 from one read of Z_0; 90 % of the sketch)",
+                              achieved=executed_gf / t_step * 1e-3, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s", frac=mfma_frac,
+                              traffic=traffic, traffic_over_algorithmic=None if traffic is None else traffic / alg,
+                              algorithmic_bytes=alg, hbm_gbs=alg / t_step * 1e-9, hbm_frac=hbm_frac,
+                              executed_gflop=executed_gf, reference_count_gflop=gflop_ref,
+                              mfma_frac_of_reference_count=gflop_ref / t_step * 1e-3 / PEAK_F64_MFMA_TF,
+                              what="executed flops (129 GF over X + 41 GF over the first left product; the recipes need 170 of the 484 GF of the "
+                                   "reference's formulation) / wall time of one sketch against the fp64 matrix peak; hbm_*: the 8.59 GB that must "
+                                   "move (the tensor once; no DRM matrix beyond 84 MB is formed) / the same time; counter traffic also holds the "
+                                   "first left product written and read once (2 x 2.7 GB) and the partial sums",
+                              unfused_77GB_rate_gbs=unfused / t_step * 1e-9))
+    return base
 
 
 # --------------------------------------------------------------------------- C4: sparse 1e7 nnz
@@ -847,7 +880,9 @@ def compact(line):
     """sub-record of a full bench line: what the judge's table needs, nothing else"""
     if line is None:
         return None
-    roof = {k: line["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "classes", "first_call_ms")
+    roof = {k: line["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes",
+                                                  "hbm_gbs", "hbm_frac", "executed_gflop", "mfma_frac_of_reference_count", "mfma_frac_of_algorithmic_flops",
+                                                  "classes", "first_call_ms", "measured_valu_gsamples")
             if line.get("roofline") and k in line["roofline"]}
     cpu = line.get("cpu_baseline")
     if cpu:
@@ -863,10 +898,10 @@ def run_extras(args, job):
     extra = {}
     sub = copy.copy(args)
     sub.steps, sub.warmup = 5, 2
-    for name, fn in (("c5", bench_c5), ("c4", bench_c4), ("c2", bench_c2)):
+    for name, fn in (("c5", bench_c5), ("c4", bench_c4), ("c2", bench_c2), ("c2_gaussian", lambda a, j: bench_c2(a, j, gaussian=True))):
         t0 = time.perf_counter()
         # (c2: a sketch is 4 ms and its first calls grow the library's scratch arenas by 1.3 GB -- a few more of both)
-        sub.steps, sub.warmup = (10, 3) if name == "c2" else (5, 2)
+        sub.steps, sub.warmup = (10, 3) if name.startswith("c2") else (5, 2)
         try:
             extra[name] = compact(fn(sub, job))
             extra[name]["bench_wall_s"] = time.perf_counter() - t0
@@ -902,7 +937,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=("c3", "c2", "c4", "c5", "ref150"), default="c3")
+    ap.add_argument("--config", choices=("c3", "c2", "c2g", "c4", "c5", "ref150"), default="c3")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--items", type=int, default=128, help="--scaling strong: TTs in the fixed job")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -917,7 +952,8 @@ def main():
         args.steps, args.warmup = 20, 3
     job = Job(args)
     try:
-        result = {"c3": bench_c3, "c2": bench_c2, "c4": bench_c4, "c5": bench_c5, "ref150": bench_ref150}[args.config](args, job)
+        result = {"c3": bench_c3, "c2": bench_c2, "c2g": lambda a, j: bench_c2(a, j, gaussian=True), "c4": bench_c4, "c5": bench_c5,
+                  "ref150": bench_ref150}[args.config](args, job)
         if (result is not None and args.config == "c3" and not args.no_extra and job.world == 1
                 and args.scaling == "weak" and not os.environ.get("TTSK_BENCH_FORCE_COMM")):
             result["extra"] = run_extras(args, job)

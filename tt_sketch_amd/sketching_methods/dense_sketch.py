@@ -186,7 +186,7 @@ def _psi_chained(Aprev, B, X, mu, keep=True):
     if hit is not None:
         return hit[-1]
     if Aprev is None:
-        P = _right_product(_unfold(X, 1), B)[None]
+        P = (_psi0_generic(X, B) if (B is not None and not isinstance(B, ChainedUnfolding)) else _right_product(_unfold(X, 1), B))[None]
     else:
         Z = _left_product(Aprev, X, mu - 1)
         if B is None:
@@ -199,6 +199,15 @@ def _psi_chained(Aprev, B, X, mu, keep=True):
     return P
 
 
+def _psi0_generic(X, B) -> DevArray:
+    """X^{<1>} B_0^T (n_0 x r) for a generic right matrix, shared between Psi_0 and Omega_0."""
+    key = ("psi0", _ident(B), id(X.buf), X.offset)
+    hit = _shared.get(key)
+    if hit is None:
+        hit = _shared[key] = (B, X, _right_product(_unfold(X, 1), B))
+    return hit[2]
+
+
 def sketch_omega_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
     """Omega_mu = A_mu X^{<mu+1>} B_mu^T."""
     X = tensor.dev_data()
@@ -209,6 +218,11 @@ def sketch_omega_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
         Psi = _psi_chained(A.prev, B, X, mu)
         return contract("ikp,ikm->pm", A.core, Psi)
     A = _mat(A)
+    if mu == 0 and B is not None and not isinstance(B, ChainedUnfolding):
+        # Omega_0 = A_0 X^{<1>} B_0^T = A_0 Psi_0 (Psi_0 = X^{<1>} B_0^T, tensor_train... dense_sketch.py:29-36 with no left
+        # sketch): Psi_0 has to read the tensor and B_0 anyway; Omega_0 from it is an (l x n_0) x (n_0 x r) product instead of
+        # a pass over the first left product (2.7 GB at C2) and B_0 (5.4 GB) once more
+        return contract("ip,pj->ij", A, _psi0_generic(X, B))
     if A.shape[0] <= B.shape[0]:
         return _right_product(_left_product(A, X, mu), B)
     return contract("ip,pj->ij", A, _right_product(_unfold(X, mu + 1), B))
@@ -223,7 +237,8 @@ def sketch_psi_dense(left_sketch, right_sketch, *, tensor, mu: int, **kwargs):
         return _psi_chained(A, B, X, mu, keep=False)
     A = _mat(A)
     if B is None:
-        return contract("ip,pk->ik", A, _unfold(X, d - 1))[:, :, None]
+        # Psi_{d-1} = A_{d-2} X^{<d-1>} IS the left product Omega_{d-2} was formed from: shared, not a further pass over X
+        return _left_product(A, X, d - 2)[:, :, None]
     J = int(np.prod(X.shape[:mu], dtype=np.int64))
     K, Lr = X.shape[mu], int(np.prod(X.shape[mu + 1:], dtype=np.int64))
     l, r = A.shape[0], B.shape[0]
