@@ -256,8 +256,9 @@ def bench_c3(args, job):
     passes = [(b0, min(B, n_mine - b0)) for b0 in range(0, n_mine, B)]
     inflight = max(1, min(int(args.inflight), nat.NUM_STREAMS // 2))
     comm_on = job.comm is not None
-    nslots = inflight if not strong else 1
-    outs = [DevArray.empty((max(n_mine, 1) * stride,)) for _ in range(nslots)]
+    # (collective path, strong too: two slots, so that the collective of step s travels under the products of step s + 1)
+    nslots = inflight if (not strong or comm_on) else 1
+    outs = [DevArray.empty((max(n_mine, 1) * stride,)) for _ in range(nslots if not strong else 1)]
     sums = [DevArray.empty((plan.size,)) for _ in range(nslots)] if comm_on else None
     keep, ptr_sets = [], []
     for b0, cnt in passes:
@@ -271,12 +272,19 @@ def bench_c3(args, job):
     cs = nat.NUM_STREAMS - 1                        # the one stream every collective goes to, in step order
     P = ctypes.c_void_p
 
+    use_reduce = getattr(args, "collective", "reduce") == "reduce"
+
     def allreduce_slot(slot, first_stream):
-        """ONE all-reduce of the rank's partial sketch (already summed over its TTs by ttsk_tt_sketch_sum)"""
+        """ONE collective of the rank's partial sketch (already summed over its TTs by ttsk_tt_sketch_sum): a REDUCE to rank 0
+        -- the rank that would assemble (to_tt); north_star's "single RCCL reduce", half the link traffic -- or, --collective
+        allreduce, the sum on every rank"""
         nat.call("ttsk_stream_wait", cs, first_stream)
         if n_mine == 0:
             nat.call("ttsk_memset", P(sums[slot].ptr), 0, ctypes.c_size_t(plan.size * 8), cs)
-        nat.call("ttsk_comm_allreduce_sum", P(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
+        if use_reduce:
+            nat.call("ttsk_comm_reduce_sum", P(sums[slot].ptr), ctypes.c_size_t(plan.size), 0, cs)
+        else:
+            nat.call("ttsk_comm_allreduce_sum", P(sums[slot].ptr), ctypes.c_size_t(plan.size), cs)
 
     def step_weak():
         slot = counter[0] % inflight
@@ -294,10 +302,12 @@ def bench_c3(args, job):
     def step_strong():
         # the whole job: this rank's passes, then (collective path) one all-reduce of the rank's partial sketch
         if comm_on:
+            slot = counter[0] % nslots
+            counter[0] += 1
             for i, (b0, cnt) in enumerate(passes):
-                plan.run_sum(ptr_sets[i], cnt, sums[0], accumulate=i > 0, stream=0)     # accumulating: one after the other
-            allreduce_slot(0, 0)
-            nat.call("ttsk_stream_wait", 0, cs)
+                plan.run_sum(ptr_sets[i], cnt, sums[slot], accumulate=i > 0, stream=2 * slot)     # accumulating: one after the other
+            allreduce_slot(slot, 2 * slot)
+            nat.call("ttsk_stream_wait", 2 * slot, cs)      # this slot's streams touch sums[slot] again only after its collective
             return
         for i, (b0, cnt) in enumerate(passes):
             st = 2 * (i % inflight)
@@ -356,7 +366,7 @@ def bench_c3(args, job):
         # same for every N: what the N = 2 test compares with the N = 1 run.
         if comm_on:
             nat.call("ttsk_sync", -1)
-            total = sums[0]                       # the all-reduced sketch of the last step
+            total = sums[(counter[0] - 1) % nslots]      # the summed sketch of the last step (after a reduce: on rank 0, which reports)
         else:
             total = DevArray.empty((plan.size + (plan.size & 1),))
             if n_mine == 0:
@@ -440,8 +450,10 @@ def bench_c3(args, job):
                                            (f"fixed job of {int(args.items)} TTs dealt over the ranks, {B} per batched pass"
                                             if strong else f"{B} TT(s) per GPU per step in one batched pass, {inflight} steps in flight") +
                                            ("; collective path: the rank's TTs are sketched as their SUM (ttsk_tt_sketch_sum: chains per TT, "
-                                            "Psi / Omega contracted over (TT, rank) in the kernels) and ONE RCCL all-reduce of one sketch per "
-                                            "step gives every rank the sketch of the whole sum" if comm_on else ""),
+                                            "Psi / Omega contracted over (TT, rank) in the kernels) and ONE RCCL " +
+                                            ("reduce of one sketch per step leaves the sketch of the whole sum on rank 0" if use_reduce else
+                                             "all-reduce of one sketch per step gives every rank the sketch of the whole sum") +
+                                            f", {nslots} steps in flight (the collective travels under the next step's products)" if comm_on else ""),
                                   d=D, n=N_MODE, tt_rank=S_IN, left_rank=L_RANK, right_rank=R_RANK,
                                   algorithmic_gflop_per_sketch=fl["total"] * 1e-9, tts_per_step=items_per_step,
                                   steps_in_flight=inflight, single_sketch_latency_ms=single_ms,
@@ -626,12 +638,21 @@ def bench_c5(args, job):
     right = tsa.TensorTrainDRM(r, shape, True, seed=2)
     S.prepare_device()
 
+    root = 0 if getattr(args, "collective", "reduce") == "reduce" else None
+
     def step():
         if job.comm is not None:
-            stream_sketch_sharded(S, (l,) * 5, (r,) * 5, job.comm, left_drm=left, right_drm=right)
-        else:
-            tsa.stream_sketch(S, (l,) * 5, (r,) * 5, left_drm=left, right_drm=right)
+            return stream_sketch_sharded(S, (l,) * 5, (r,) * 5, job.comm, left_drm=left, right_drm=right, root=root)
+        return tsa.stream_sketch(S, (l,) * 5, (r,) * 5, left_drm=left, right_drm=right)
     elapsed = job.timed(step, args.steps, args.warmup)
+    check = None
+    if args.check:
+        # the sketch of the whole sum as rank 0 holds it (the same for every N: what the N = 2 test compares with N = 1)
+        stt = step()
+        h = np.concatenate([np.asarray(a).ravel() for a in stt.Psi_cores + stt.Omega_mats])
+        probe = np.random.default_rng(12345).standard_normal(h.size)
+        check = dict(norm=float(np.linalg.norm(h)), probe=float(h @ probe), head=[float(x) for x in h[:4]], size=int(h.size))
+        job.barrier()
     if job.rank != 0:
         return None
     fl = algorithmic_flops(shape, (s,) * 5, (l,) * 5, (r,) * 5)
@@ -654,7 +675,7 @@ def bench_c5(args, job):
                               frac=gf / t_step * 1e-12 / PEAK_F64_MFMA_TF, traffic=None,
                               what="algorithmic flops of the 32 term sketches (SURVEY 8d: 0.443 GF each) / wall time of one "
                                    "stream_sketch call incl. Python"),
-                cpu_baseline=cpu)
+                cpu_baseline=cpu, **({"sketch_check": check} if check is not None else {}))
 
 
 # --------------------------------------------------------------------------- C2: dense d=5 n=64
@@ -938,7 +959,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=("c3", "c2", "c2g", "c4", "c5", "ref150"), default="c3")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: weak on one GPU; with --gpus N > 1 the headline is the STRONG job (north_star's quantity) and the "
+                         "weak number rides along as a sub-record")
+    ap.add_argument("--collective", choices=("reduce", "allreduce"), default="reduce",
+                    help="collective path: one reduce to rank 0 (default) or an all-reduce")
     ap.add_argument("--items", type=int, default=128, help="--scaling strong: TTs in the fixed job")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", action="store_true",
@@ -952,11 +977,24 @@ def main():
         args.steps, args.warmup = 20, 3
     job = Job(args)
     try:
+        both = args.scaling is None and args.config == "c3" and job.world > 1
+        if args.scaling is None:
+            args.scaling = "strong" if both else "weak"
         result = {"c3": bench_c3, "c2": bench_c2, "c2g": lambda a, j: bench_c2(a, j, gaussian=True), "c4": bench_c4, "c5": bench_c5,
                   "ref150": bench_ref150}[args.config](args, job)
         if (result is not None and args.config == "c3" and not args.no_extra and job.world == 1
                 and args.scaling == "weak" and not os.environ.get("TTSK_BENCH_FORCE_COMM")):
             result["extra"] = run_extras(args, job)
+        if both:
+            # the same launch also measures the weak job (per-GPU work fixed): a sub-record of the one line
+            import copy
+            sub = copy.copy(args)
+            sub.scaling, sub.no_cpu, sub.check = "weak", True, False
+            sub.steps, sub.warmup = min(args.steps, 60), min(args.warmup, 10)
+            weak = bench_c3(sub, job)
+            if result is not None and weak is not None:
+                result["weak"] = {k: weak[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling")}
+                result["weak"]["workload"] = weak["config"]["workload"]
         if result is not None:
             print(json.dumps(result))
     finally:

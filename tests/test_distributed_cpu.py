@@ -32,7 +32,12 @@ def _gloo_comm(dist, rank, world):
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         return [o.numpy() for o in outs]
-    return HostComm(rank, world, allreduce, allgather)
+
+    def reduce(buf, root):
+        t = torch.from_numpy(np.array(buf, dtype=np.float64))
+        dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+        return t.numpy() if rank == root else np.array(buf, dtype=np.float64)     # (gloo leaves partial sums on the others)
+    return HostComm(rank, world, allreduce, allgather, reduce)
 
 
 def _oracle_drm(d):
@@ -121,7 +126,13 @@ def _worker(rank, world, port, outdir):
     results["blocked"] = max(float(np.max(np.abs(a - b))) for a, b in
                              zip(blk.Psi_cores + blk.Omega_mats, ref.Psi_cores + ref.Omega_mats))   # placement: exact
     results["blocked_vs_whole"] = _maxrel(blk, _oracle_sketch(sp, hl, hr))     # blocked == unblocked (reference tests :137-187)
-    np.save(os.path.join(outdir, f"r{rank}.npy"), np.array([results[k] for k in ("tt_sum", "sparse", "one_term", "blocked_vs_whole", "blocked")]))
+    # (5) the single REDUCE to the rank that assembles (north_star: "a single RCCL reduce"): rank 1 holds the sketch of the
+    # whole sum, rank 0 keeps its own partial sketch
+    stt = stream_sketch_sharded(whole, l, r, comm, left_drm=left, right_drm=right, sketch_fn=_oracle_sketch, root=1)
+    mine = shard_tensor(whole, rank, world)
+    want = _oracle_sketch(whole, left, right) if rank == 1 else _oracle_sketch(mine, left, right)
+    results["reduce_root"] = _maxrel(stt.sketch_, want)
+    np.save(os.path.join(outdir, f"r{rank}.npy"), np.array([results[k] for k in ("tt_sum", "sparse", "one_term", "blocked_vs_whole", "reduce_root", "blocked")]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -140,8 +151,8 @@ def test_two_rank_partial_sketch_sum(tmp_path):
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
     for rank in range(2):
         errs = np.load(tmp_path / f"r{rank}.npy")
-        assert np.all(errs[:4] < 1e-12), errs
-        assert errs[4] == 0.0, errs          # placement moves blocks, it adds nothing
+        assert np.all(errs[:5] < 1e-12), errs
+        assert errs[5] == 0.0, errs          # placement moves blocks, it adds nothing
 
 
 if __name__ == "__main__":

@@ -236,6 +236,19 @@ def test_two_gpus_give_the_one_gpu_sketch():
     assert abs(ca["probe"] - cb["probe"]) <= 1e-11 * ca["norm"] * (a["config"]["sketch_bytes"] / 8) ** 0.5
     for x, y in zip(ca["head"], cb["head"]):
         assert abs(x - y) <= 1e-12 * max(abs(x), 1e-300) + 1e-12 * ca["norm"] * 1e-3
+    # the same for C5 -- the configuration north_star spreads term-per-GPU: 32 terms dealt over the ranks, one reduce
+    c5 = ["--config", "c5", "--steps", "2", "--warmup", "1", "--no-cpu", "--check"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + c5, capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port + 1), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + c5,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, (two.stdout[-1000:], two.stderr[-3000:])
+    ca = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])["sketch_check"]
+    cb = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])["sketch_check"]
+    assert abs(ca["norm"] - cb["norm"]) <= 1e-12 * ca["norm"]
+    assert abs(ca["probe"] - cb["probe"]) <= 1e-11 * ca["norm"] * ca["size"] ** 0.5
 
 
 def test_strong_scaling_check_runs_on_one_gpu():
@@ -245,14 +258,24 @@ def test_strong_scaling_check_runs_on_one_gpu():
     common = ["--gpus", "1", "--scaling", "strong", "--items", "8", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu", "--check"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = []
-    for force in (False, True):
+    for force, coll in ((False, "reduce"), (True, "reduce"), (True, "allreduce")):
         e = dict(env, TTSK_BENCH_FORCE_COMM="1") if force else env
         try:
-            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300,
-                                 env=e, cwd=ROOT)
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--collective", coll], capture_output=True,
+                                 text=True, timeout=300, env=e, cwd=ROOT)
         except subprocess.TimeoutExpired as exc:
-            pytest.fail(f"bench.py --check (force_comm={force}) did not finish: {exc}")
+            pytest.fail(f"bench.py --check (force_comm={force}, {coll}) did not finish: {exc}")
         assert res.returncode == 0, res.stderr[-3000:]
         outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])["sketch_check"])
-    assert abs(outs[0]["norm"] - outs[1]["norm"]) <= 1e-13 * outs[0]["norm"]
-    assert outs[0]["head"] == outs[1]["head"]
+    for o in outs[1:]:
+        assert abs(outs[0]["norm"] - o["norm"]) <= 1e-13 * outs[0]["norm"]
+        assert outs[0]["head"] == o["head"]
+    # C5 with the collective path forced on one rank: the reduce leaves the sum of all 32 terms on rank 0
+    c5 = ["--gpus", "1", "--config", "c5", "--steps", "2", "--warmup", "1", "--no-cpu", "--check"]
+    c5o = []
+    for force in (False, True):
+        e = dict(env, TTSK_BENCH_FORCE_COMM="1") if force else env
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + c5, capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+        assert res.returncode == 0, res.stderr[-3000:]
+        c5o.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])["sketch_check"])
+    assert abs(c5o[0]["norm"] - c5o[1]["norm"]) <= 1e-13 * c5o[0]["norm"]

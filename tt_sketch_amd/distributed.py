@@ -63,9 +63,10 @@ class HostComm:
     on_device = False
 
     def __init__(self, rank: int, world: int, allreduce: Callable[[np.ndarray], np.ndarray],
-                 allgather: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None):
+                 allgather: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None,
+                 reduce: Optional[Callable[[np.ndarray, int], np.ndarray]] = None):
         self.rank, self.world = int(rank), int(world)
-        self._allreduce, self._allgather = allreduce, allgather
+        self._allreduce, self._allgather, self._reduce = allreduce, allgather, reduce
 
     @classmethod
     def over_files(cls, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0) -> "HostComm":
@@ -91,6 +92,15 @@ class HostComm:
 
     def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
         return np.asarray(self._allreduce(np.ascontiguousarray(buf, dtype=np.float64)))
+
+    def reduce_sum(self, buf: np.ndarray, root: int = 0) -> np.ndarray:
+        """The sum on ``root``; the other ranks get their own buffer back (as an RCCL reduce leaves it).  Carried by the
+        all-reduce the caller supplied, or by ``reduce`` when one was given."""
+        fn = getattr(self, "_reduce", None)
+        if fn is not None:
+            return np.asarray(fn(np.ascontiguousarray(buf, dtype=np.float64), root))
+        out = self.allreduce_sum(buf)
+        return out if self.rank == root else np.ascontiguousarray(buf, dtype=np.float64)
 
     def allgather(self, buf: np.ndarray) -> List[np.ndarray]:
         if self._allgather is None:
@@ -230,14 +240,17 @@ def unpack_device(buf: DevArray, shape, left_rank, right_rank) -> SketchContaine
     return SketchContainer(out[:d], out[d:], tuple(shape), tuple(left_rank), tuple(right_rank))
 
 
-def allreduce_container(local: SketchContainer, comm) -> SketchContainer:
+def allreduce_container(local: SketchContainer, comm, root: Optional[int] = None) -> SketchContainer:
     """Sum the ranks' partial sketches with ONE collective of the packed buffer
-    (``SketchContainer.__add__`` across ranks, reference sketch_container.py:61-69)."""
+    (``SketchContainer.__add__`` across ranks, reference sketch_container.py:61-69).  ``root``: a single REDUCE to that
+    rank (half the link traffic of the all-reduce; what a job needs whose assembly -- ``to_tt`` -- runs on one rank):
+    the container is then the whole sum on ``root`` and the rank's own partial sketch elsewhere."""
     if getattr(comm, "on_device", False):
         Psi, Om = local.device_arrays()
-        buf = comm.allreduce_sum(pack_device(Psi, Om))
+        buf = pack_device(Psi, Om)
+        buf = comm.allreduce_sum(buf) if root is None else comm.reduce_sum(buf, root)
         return unpack_device(buf, local.shape, local.left_rank, local.right_rank)
-    return local.unpack(comm.allreduce_sum(local.pack()))
+    return local.unpack(comm.allreduce_sum(local.pack()) if root is None else comm.reduce_sum(local.pack(), root))
 
 
 def _device_sketch(tensor, left_drm, right_drm) -> SketchContainer:
@@ -247,11 +260,13 @@ def _device_sketch(tensor, left_drm, right_drm) -> SketchContainer:
 
 def stream_sketch_sharded(tensor: Tensor, left_rank, right_rank, comm, seed: Optional[int] = None,
                           left_drm_type=None, right_drm_type=None, left_drm=None, right_drm=None,
-                          sketch_fn: Optional[Callable] = None):
+                          sketch_fn: Optional[Callable] = None, root: Optional[int] = None):
     """``stream_sketch`` of a TensorSum / SparseTensor whose additive pieces are dealt over the ranks of
     ``comm``: every rank sketches its share with the same DRMs, one all-reduce sums the packed partial
     sketches, every rank returns the ``SketchedTensorTrain`` of the WHOLE tensor
     (reference sketch.py:154-229 for the argument policy, sketch_dispatch.py:85-147 for the sum).
+    ``root``: one REDUCE instead -- only that rank holds the sketch of the whole tensor (the others return their partial
+    sketch), at half the link traffic.
 
     The DRMs must be identical on all ranks: pass ``seed`` (the device samplers are pure functions of
     it) or the DRM objects.  ``sketch_fn(shard, left_drm, right_drm) -> SketchContainer`` replaces the
@@ -282,7 +297,7 @@ def stream_sketch_sharded(tensor: Tensor, left_rank, right_rank, comm, seed: Opt
         local = fn(mine, left_drm, right_drm)
     else:
         local = SketchContainer.zero(tensor.shape, tuple(left_drm.rank), tuple(right_drm.rank[::-1]))
-    total = allreduce_container(local, comm)
+    total = allreduce_container(local, comm, root)
     return SketchedTensorTrain(total, left_drm, right_drm)
 
 
