@@ -803,10 +803,12 @@ def bench_c4(args, job):
     nat.call("ttsk_prof_enable", 0)
     from tt_sketch_amd import sparse_fused
     plan = dict(sparse_fused.last_plan)
-    # VALU roof of a Gaussian sample: hash (two 64 x 64-bit multiplies = 6 quarter-rate 32-bit multiplies + ~20 integer
-    # ops) + ndtri (central branch: 13 FMAs + a division; tails, 27 %: two logs, a square root, three divisions, 18 FMAs):
-    # ~400 SIMD cycles per 64 samples -> 256 CUs x 4 SIMDs x 2.4 GHz x 64 / 400 = 393 G samples / s
-    VALU_GSAMPLES = 393.0
+    # VALU roof of a Gaussian sample, MEASURED on this device (ttsk_ndtri_rate_probe: hash + ndtri with the kernels' central / tail
+    # split on resident operands, nothing else; [1] = every lane through both branches).  (Rounds 2-3 priced against an
+    # instruction-count estimate of 393 G samples / s.)
+    probe = (ctypes.c_double * 2)()
+    nat.call("ttsk_ndtri_rate_probe", probe)
+    VALU_GSAMPLES = float(probe[0])
     for label, c in classes.items():
         work = c.pop("gflop_per_launch") * 1e9          # the class's own work unit per launch
         c.pop("tflops", None)
@@ -847,6 +849,7 @@ def bench_c4(args, job):
                               what="SURVEY 8d bytes 8*nnz*(d+1) = 480 MB / wall time of one sketch (the per-class entry prices the passes "
                                    "against the fp64 VALU, which binds: every DRM row of a deep mode is an ndtri evaluation)",
                               gaussian_samples_per_s=samples / t_step, classes=classes,
+                              measured_valu_gsamples=dict(split=float(probe[0]), divergent=float(probe[1])),
                               first_call_ms=dict(h2d_and_upload=t_h2d * 1e3, first_sketch_incl_mode_sorts=t_first * 1e3,
                                                  steady_state=t_step * 1e3)),
                 cpu_baseline=cpu)

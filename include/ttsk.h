@@ -173,6 +173,11 @@ int ttsk_prof_enable(int on);
  * row, so bench.py states this number next to the 78.6 TF/s data-sheet value (it measures 77.7 at 2.4 GHz:
  * one instruction per 64 cycles and SIMD; sustained kernels run at a lower clock). */
 int ttsk_mfma_f64_peak_probe(double *tflops);
+/* measured ceiling of the hash-Gaussian sampler's arithmetic on this device (fast_lazy_gaussian.pyx:23-49,91-105: the 64-bit
+ * mix, the forced-exponent bits, Cephes ndtri), operands resident, no memory traffic: gsamples[0] with the central / tail
+ * split of the sampling kernels (tail samples queued and evaluated a full wave at a time), gsamples[1] every lane through
+ * ndtri as it comes.  10^9 samples / s.  bench.py prices the sampling passes of the sparse sketch against [0]. */
+int ttsk_ndtri_rate_probe(double *gsamples);
 /* class 0/1: right-chain GEMM1 (T = R^T X^T) / GEMM2 (split-K); 2/3: left-chain GEMM1 / GEMM2;
  * 4: Psi GEMM; 5: small products (Omega, first mode); 7: untagged ttsk_gemm calls.  Only the main
  * contraction kernel of each call is bracketed (not the split-K reduce / zero fill) -- except for the fused

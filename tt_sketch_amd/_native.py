@@ -68,6 +68,7 @@ def _bind(lib):
                                 P, c_int64, c_int64, c_int64, POINTER(P), I],
         "ttsk_prof_enable": [I],
         "ttsk_mfma_f64_peak_probe": [POINTER(c_double)],
+        "ttsk_ndtri_rate_probe": [POINTER(c_double)],
         "ttsk_prof_read": [I, POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
         "ttsk_prof_kernel_name": [I, c_char_p, S],
         "ttsk_hash_u64": [P, S],

@@ -211,6 +211,62 @@ __global__ __launch_bounds__(256) void fill_normal_many_kernel(FillMany a)
     fill_normal_body(a.out[seg], a.n[seg], a.key[seg], a.scale[seg]);
 }
 
+// What the chip gives for hash + ndtri and nothing else (the ceiling the sampling passes of the sparse
+// sketch are priced against, instead of an instruction-count estimate).  Same device code as the kernels (mix64, mant_unit,
+// ndtri_dev), the same split they use -- central branch in place, tail samples queued per wave by ballot and evaluated a full
+// wave at a time -- operands in registers / LDS, no global traffic but one checksum per lane; the 73 / 27 central / tail mix is
+// the uniform distribution's.  MODE 1: every lane evaluates ndtri_dev as it comes (both branches under divergence).
+constexpr int PROBE_COLS = 16;
+template <int MODE>
+__global__ __launch_bounds__(256) void ndtri_probe_kernel(double *sink, int reps, uint64_t seed)
+{
+    __shared__ double tile[4][64 * PROBE_COLS];
+    __shared__ unsigned short tq[4][64 * PROBE_COLS];
+    __shared__ uint64_t salt[PROBE_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < PROBE_COLS) salt[tid] = mix64((uint64_t)tid) + seed;
+    __syncthreads();
+    double *T = tile[wv];
+    unsigned short *q = tq[wv];
+    const uint64_t row0 = ((uint64_t)blockIdx.x * 256 + tid) * (uint64_t)reps;
+    const double expm2 = 0.13533528323661269189;
+    double acc = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const uint64_t flat = row0 + r;
+        int qn = 0;
+#pragma unroll 4
+        for (int c = 0; c < PROBE_COLS; ++c) {
+            const uint64_t h = mix64(flat + salt[c]);
+            const double u = mant_unit((h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL);
+            if (MODE == 1) {
+                acc += ndtri_dev(u);
+            } else {
+                const int slot = lane * PROBE_COLS + c;
+                const bool central = u > expm2 && u <= 1.0 - expm2;
+                if (central) T[slot] = ndtri_dev(u);
+                const unsigned long long m = __ballot(!central);
+                if (!central) {
+                    T[slot] = u;
+                    q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)slot;
+                }
+                qn += __popcll(m);
+            }
+        }
+        if (MODE == 0) {
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < qn; i += 64)
+                if (i + lane < qn) {
+                    const int slot = q[i + lane];
+                    T[slot] = ndtri_dev(T[slot]);
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int c = 0; c < PROBE_COLS; ++c) acc += T[lane * PROBE_COLS + c];
+        }
+    }
+    sink[(size_t)blockIdx.x * 256 + tid] = acc;
+}
+
 static unsigned grid_for(size_t n, unsigned block = 256, unsigned cap = 16384)
 {
     size_t b = (n + block - 1) / block;
@@ -279,6 +335,38 @@ static int sign_dev(const int64_t *dev_idx, const IndexMap &im, size_t N, int tr
 using namespace ttsk;
 
 extern "C" {
+
+// Gaussian samples per second of the hash + ndtri code on this device: [0] with the kernels' central / tail split, [1] every
+// lane through both branches (what a plain per-lane ndtri costs under divergence).  G samples / s.
+int ttsk_ndtri_rate_probe(double *gsamples)
+{
+    TTSK_STREAM(st, 0);
+    TTSK_ARG(gsamples, "ttsk_ndtri_rate_probe: NULL");
+    const int blocks = 256 * 8, reps = 256;
+    double *sink = (double *)scratch(0, SCRATCH_MISC, (size_t)blocks * 256 * 8);
+    if (!sink) return TTSK_ERR_HIP;
+    hipEvent_t a, b;
+    TTSK_HIP(hipEventCreate(&a));
+    TTSK_HIP(hipEventCreate(&b));
+    for (int mode = 0; mode < 2; ++mode) {
+        double best = 0;
+        for (int rep = 0; rep < 4; ++rep) {
+            TTSK_HIP(hipEventRecord(a, st));
+            if (mode == 0) hipLaunchKernelGGL((ndtri_probe_kernel<0>), dim3(blocks), dim3(256), 0, st, sink, reps, (uint64_t)(17 + rep));
+            else hipLaunchKernelGGL((ndtri_probe_kernel<1>), dim3(blocks), dim3(256), 0, st, sink, reps, (uint64_t)(17 + rep));
+            TTSK_HIP(hipEventRecord(b, st));
+            TTSK_HIP(hipEventSynchronize(b));
+            float ms = 0;
+            TTSK_HIP(hipEventElapsedTime(&ms, a, b));
+            const double rate = (double)blocks * 256 * reps * PROBE_COLS / (ms * 1e-3) * 1e-9;
+            if (rep > 0 && rate > best) best = rate;
+        }
+        gsamples[mode] = best;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return TTSK_OK;
+}
 
 int ttsk_hash_u64(uint64_t *host_vals, size_t n)
 {
