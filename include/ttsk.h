@@ -162,6 +162,14 @@ int ttsk_chain_step_sum(int nb, int n, int K1, int A, int A2, int J, const doubl
                         const double *const *X, int64_t x_j, int64_t x_k, int64_t x_c, int64_t x_extent,
                         const double *E, double *T, int64_t t_b, int64_t t_ld, int64_t t_extent,
                         double *const *Out, int stream);
+/* Dense tensor x DRM MATRICES (dense_gaussian_drm.py:77-80, dense_sketch.py:7-52): the first four left products
+ * Z_mu = A_mu X^{<mu+1>}, mu = 0..3, from ONE read of X viewed as (n0, n1, n2, C = n3 * n4) (csrc/dense_left_pass.hip).
+ * A0 (l, n0) and A3 (l, n0 n1 n2 n3) as the DRM holds them, A1t (l, n1, n0) / A2t (l, n2, n1, n0) the transposed copies of
+ * A_1 / A_2; Z0 (l, n1 n2 C), Z1 (l, n2 C), Z2 (l, C); E3 (l, C) still holds i3: Z_3[a, i4] = sum_{i3} E3[a, (i3, i4)].
+ * TTSK_ERR_UNSUPPORTED outside the cover (n0 % 4, C % 512, n4 in {64, 128, 256, 512}, l <= 20). */
+int ttsk_dense_left_pass(const double *X, int64_t n0, int64_t n1, int64_t n2, int64_t C, int64_t n4, int l,
+                         const double *A0, const double *A1t, const double *A2t, const double *A3, double *Z0, double *Z1,
+                         double *Z2, double *E3, int stream);
 /* number of doubles ttsk_tt_sketch writes to `out` */
 int64_t ttsk_tt_sketch_size(int d, const int64_t *n, const int64_t *l_lo, const int64_t *l_hi,
                             const int64_t *r_lo, const int64_t *r_hi);

@@ -103,3 +103,78 @@ def test_dense_sketch_with_the_first_pass_vs_oracle(tsa, monkeypatch, shape, l, 
     two = tsa.general_sketch(tsa.DenseTensor(X), left, right, tsa.SketchMethod.streaming)
     for got, want in zip(list(sk.Psi_cores) + list(sk.Omega_mats), list(two.Psi_cores) + list(two.Omega_mats)):
         assert _rel(got, want) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# ttsk_dense_left_pass: DRM MATRICES on the left (DenseGaussianDRM): Z_0 .. Z_3 from one read of the tensor
+LEFT_SHAPES = [
+    # (n0, n1, n2, n3, n4, l)
+    (8, 3, 8, 8, 64, 20),        # i2 dealt over the XCDs, one column tile, strip rows 16..19
+    (4, 2, 5, 16, 64, 20),       # n2 not a multiple of 8 (plain block map), two column tiles
+    (12, 5, 3, 4, 128, 7),       # no strip, n4 = 128: four i3 per column tile
+    (16, 2, 2, 2, 512, 16),      # n4 = 512: one i3 per tile, two tiles
+    (8, 4, 8, 2, 256, 17),
+    (64, 2, 8, 8, 64, 20),       # the C2 first mode
+]
+
+
+@pytest.mark.parametrize("n0,n1,n2,n3,n4,l", LEFT_SHAPES)
+def test_left_pass_against_einsum(tsa, n0, n1, n2, n3, n4, l):
+    """the four left products of dense_sketch.py:15-16 / :40-51 with the matrices of dense_gaussian_drm.py:77-80"""
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray, as_dev, sync
+    rng = np.random.default_rng(n0 + n1 + n2 + n3 + n4 + l)
+    X = rng.standard_normal((n0, n1, n2, n3, n4))
+    A = [rng.standard_normal((l, int(np.prod(X.shape[:mu + 1])))) for mu in range(4)]
+    C = n3 * n4
+    Xd = as_dev(X)
+    A0 = as_dev(A[0])
+    A3 = as_dev(np.ascontiguousarray(A[3].reshape(l, n0, n1, n2, n3).transpose(0, 3, 2, 4, 1)))
+    A1t = as_dev(np.ascontiguousarray(A[1].reshape(l, n0, n1).transpose(0, 2, 1)))
+    A2t = as_dev(np.ascontiguousarray(A[2].reshape(l, n0, n1, n2).transpose(0, 3, 2, 1)))
+    Z0, Z1, Z2, E3 = (DevArray.empty(s) for s in ((l, n1 * n2 * C), (l, n2 * C), (l, C), (l, C)))
+    V = ctypes.c_void_p
+    nat.call("ttsk_dense_left_pass", V(Xd.ptr), n0, n1, n2, C, n4, l, V(A0.ptr), V(A1t.ptr), V(A2t.ptr), V(A3.ptr), V(Z0.ptr),
+             V(Z1.ptr), V(Z2.ptr), V(E3.ptr), 0)
+    sync()
+    want = [A[mu] @ X.reshape(A[mu].shape[1], -1) for mu in range(4)]
+    assert _rel(Z0.get(), want[0]) < 1e-13
+    assert _rel(Z1.get(), want[1]) < 1e-13
+    assert _rel(Z2.get(), want[2]) < 1e-13
+    assert _rel(E3.get().reshape(l, n3, n4).sum(axis=1), want[3]) < 1e-13
+
+
+def test_left_pass_declines_outside_its_cover(tsa):
+    from tt_sketch_amd import _native as nat
+    from tt_sketch_amd.device import DevArray
+    V = ctypes.c_void_p
+    d = DevArray.zeros((64,))
+    for (n0, n1, n2, C, n4, l) in [(6, 2, 2, 512, 64, 8), (8, 2, 2, 500, 50, 8), (8, 2, 2, 512, 32, 8), (8, 2, 2, 512, 64, 21)]:
+        with pytest.raises(nat.TtskUnsupported):
+            nat.call("ttsk_dense_left_pass", V(d.ptr), n0, n1, n2, C, n4, l, V(d.ptr), V(d.ptr), V(d.ptr), V(d.ptr), V(d.ptr),
+                     V(d.ptr), V(d.ptr), V(d.ptr), 0)
+
+
+@pytest.mark.parametrize("shape,l,r", [((8, 3, 8, 8, 64), 6, 9), ((4, 4, 3, 16, 64), 20, 22), ((8, 2, 2, 8, 8, 8), 5, 7)])
+def test_dense_gaussian_sketch_with_the_left_pass_vs_oracle(tsa, monkeypatch, shape, l, r):
+    """general_sketch of a dense tensor with DenseGaussianDRMs of order 5 / 6 (the last modes merged behind the fourth): the
+    fused left pass and the mode-by-mode path both against the oracle (dense_sketch.py:7-52 as the reference writes it),
+    incl. Omega_0 = A_0 Psi_0 and Psi_{d-1} from the shared left product."""
+    from tt_sketch_amd.sketching_methods import dense_sketch
+    rng = np.random.default_rng(sum(shape) + l)
+    d = len(shape)
+    X = rng.standard_normal(shape)
+    left = tsa.DenseGaussianDRM(l, shape, False, seed=5)
+    right = tsa.DenseGaussianDRM(r, shape, True, seed=6)
+    ld = orc.DenseDrm([np.asarray(m) for m in left.sketching_mats], shape, False)
+    rd = orc.DenseDrm([np.asarray(m) for m in right.sketching_mats], shape, True)
+    oP, oO = orc.general_sketch("dense", X, ld, rd, "streaming")
+    hits = []
+    real = dense_sketch.prepare_left
+    monkeypatch.setattr(dense_sketch, "prepare_left", lambda *a, **k: hits.append(real(*a, **k)) or hits[-1])
+    for on in ("1", "0"):
+        monkeypatch.setenv("TTSK_DENSE_LEFT_PASS", on)
+        sk = tsa.general_sketch(tsa.DenseTensor(X), left, right, tsa.SketchMethod.streaming)
+        for a, b in zip(sk.Psi_cores + sk.Omega_mats, oP + oO):
+            assert a.shape == b.shape and np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b)
+    assert hits == [True, False]

@@ -100,6 +100,7 @@ def _bind(lib):
         "ttsk_pinv_batch_deferred": [I, POINTER(P), c_int64, c_int64, POINTER(P), I],
         "ttsk_pinv_batch": [I, POINTER(P), c_int64, c_int64, POINTER(P), I],
         "ttsk_dense_first_pass": [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, P, I],
+        "ttsk_dense_left_pass": [P, c_int64, c_int64, c_int64, c_int64, c_int64, I, P, P, P, P, P, P, P, P, I],
         "ttsk_orth_step_pinv": [P, c_int64, c_int64, P, c_int64, P, I],
         "ttsk_tt_orth_sketch": [I] + [POINTER(c_int64)] * 4 + [POINTER(P)] * 5 + [I],
         "ttsk_tt_assemble": [I] + [POINTER(c_int64)] * 3 + [POINTER(P)] * 4 + [I, I],

@@ -248,6 +248,9 @@ def _sketch_pass(tensor: Tensor, left_drm: Optional[DRM], right_drm: DRM, method
     right_rank = tuple(right_drm.rank[::-1])
 
     Omega_mats: List[DevArray] = []
+    if method != SketchMethod.hmt and type(tensor) is DenseTensor:
+        from .sketching_methods import dense_sketch
+        dense_sketch.prepare_left(tensor, left_contractions)     # DRM matrices: the left products from one read of the tensor
     if method != SketchMethod.hmt:
         omega_method = OMEGA_METHODS[type(tensor)]
         for mu in range(d - 1):

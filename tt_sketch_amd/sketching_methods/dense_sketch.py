@@ -23,6 +23,7 @@ import numpy as np
 from ..device import DevArray, as_dev, contract
 
 _shared = {}     # key -> (objects the key's ids refer to ..., product); cleared by general_sketch_device
+_perm_cache = {}  # (buffer of a DRM matrix A_3, view) -> (that buffer, its transposed copy for ttsk_dense_left_pass)
 
 
 def clear_shared() -> None:
@@ -79,6 +80,52 @@ def _ident(x):
     if x is None or isinstance(x, ChainedUnfolding):
         return id(x)
     return (id(x.buf), x.offset, x.shape, x.strides)
+
+
+def prepare_left(tensor, left_contractions) -> bool:
+    """DRM MATRICES on the left (DenseGaussianDRM, plug-ins), order >= 5: the first four left products Z_mu = A_mu X^{<mu+1>}
+    from ONE read of the tensor (``ttsk_dense_left_pass``) instead of one pass each; they land in ``_shared`` under the
+    keys ``_left_product`` looks them up by.  Called by ``general_sketch`` before the Omega loop."""
+    import ctypes
+    from .. import _native as nat
+    if os.environ.get("TTSK_DENSE_LEFT_PASS", "1") == "0":
+        return False
+    X = tensor.dev_data()
+    A = [_norm(x) for x in left_contractions]
+    if X.ndim < 5 or len(A) < 4 or any(isinstance(a, ChainedUnfolding) or a is None for a in A[:4]) or not X.is_contiguous():
+        return False
+    n0, n1, n2, n3 = (int(v) for v in X.shape[:4])
+    n4 = int(np.prod(X.shape[4:], dtype=np.int64))
+    l = int(A[0].shape[0])
+    C = n3 * n4
+    if any(int(A[mu].shape[0]) != l for mu in range(4)) or l > 20 or n0 % 4 or C % 512 or n4 not in (64, 128, 256, 512):
+        return False
+    if [tuple(A[mu].shape) for mu in range(4)] != [(l, n0), (l, n0 * n1), (l, n0 * n1 * n2), (l, n0 * n1 * n2 * n3)]:
+        return False
+    A0 = A[0].contiguous()
+    # the transposed copies the pass reads (i0 fastest).  That of A_3 is as large as A_3 itself (2.7 GB at C2): kept with the
+    # matrix it was made from for as long as that matrix lives (a DRM reused over many sketches pays for it once)
+    A1t = A[1].reshape(l, n0, n1).transpose(0, 2, 1).contiguous()
+    A2t = A[2].reshape(l, n0, n1, n2).transpose(0, 3, 2, 1).contiguous()
+    key = (id(A[3].buf), A[3].offset, tuple(A[3].shape), tuple(A[3].strides))
+    hit = _perm_cache.get(key)
+    if hit is None or hit[0] is not A[3].buf:
+        if len(_perm_cache) >= 4:
+            _perm_cache.clear()
+        hit = _perm_cache[key] = (A[3].buf, A[3].reshape(l, n0, n1, n2, n3).transpose(0, 3, 2, 4, 1).contiguous())
+    A3 = hit[1]
+    Z0, Z1 = DevArray.empty((l, n1 * n2 * C)), DevArray.empty((l, n2 * C))
+    Z2, E3 = DevArray.empty((l, C)), DevArray.empty((l, C))
+    V = ctypes.c_void_p
+    try:
+        nat.call("ttsk_dense_left_pass", V(X.ptr), n0, n1, n2, C, n4, l, V(A0.ptr), V(A1t.ptr), V(A2t.ptr), V(A3.ptr), V(Z0.ptr),
+                 V(Z1.ptr), V(Z2.ptr), V(E3.ptr), 0)
+    except nat.TtskUnsupported:
+        return False
+    Z3 = contract("aij,i->aj", E3.reshape(l, n3, n4), DevArray.from_host(np.ones(n3)))
+    for mu, Z in enumerate((Z0, Z1, Z2, Z3)):
+        _shared[("left", _ident(A[mu]), id(X.buf), X.offset, mu)] = (A[mu], X, Z)
+    return True
 
 
 def _left_product(A, X, mu):
