@@ -178,3 +178,20 @@ def test_dense_gaussian_sketch_with_the_left_pass_vs_oracle(tsa, monkeypatch, sh
         for a, b in zip(sk.Psi_cores + sk.Omega_mats, oP + oO):
             assert a.shape == b.shape and np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b)
     assert hits == [True, False]
+
+
+@pytest.mark.parametrize("rows,N,K,pad", [(64, 40, 8192, 0), (20, 40, 4096, 0), (130, 7, 12288, 64), (1, 48, 4160, 0), (200, 33, 6400, 2),
+                                          (64, 16, 4096, 0), (70, 36, 65536, 0)])
+def test_rows_against_a_matrix_long_k(tsa, rows, N, K, pad):
+    """C = S B^T with both operands contiguous along a long contracted index (the right-hand products of a dense sketch with
+    DRM matrices, dense_sketch.py:15-16): rows_longk_kernel behind ttsk_gemm / contract, against numpy; row blocks of 64 with a
+    short last block, 1 .. 48 matrix rows (tiles + 4-wide strips, odd counts), operands that are row views of wider arrays."""
+    from tt_sketch_amd.device import as_dev, contract, sync
+    rng = np.random.default_rng(rows + N + K)
+    S = rng.standard_normal((rows, K + pad))
+    B = rng.standard_normal((N, K + pad))
+    Sd, Bd = as_dev(S)[:, :K], as_dev(B)[:, :K]
+    C = contract("bq,mq->bm", Sd, Bd)
+    sync()
+    want = S[:, :K] @ B[:, :K].T
+    assert _rel(C.get(), want) < 1e-13

@@ -73,6 +73,10 @@ void prof_close(hipStream_t st);
 enum { PROF_SAMPLER = 6, PROF_SPARSE = 7, PROF_SOLVE = 8 };
 void prof_open_named(hipStream_t st, int cls, double work, const char *name);   // work in the class's own unit
 
+// dense_right_pass.hip: C[m][n] (+)= alpha sum_k S[m][k] B[n][k], both rows contiguous along a long k, n <= 48: 1 = launched, 0 = not covered
+int rows_longk_try(const double *S, int64_t rows, int64_t s_row, const double *B, int N, int64_t b_row, int64_t K, double *C,
+                   int64_t c_row, double alpha, int accumulate, int stream, hipStream_t st);
+
 // svd_grid.hip: one-sided Jacobi SVD over all compute units (n beyond the one-workgroup kernel)
 int svd_jacobi_grid(const double *A, int64_t m, int64_t n, double *US, double *S, double *Vt, int stream, hipStream_t st);
 

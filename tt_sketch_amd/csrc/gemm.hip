@@ -213,6 +213,18 @@ int ttsk_gemm(const ttsk_gemm_desc *dp, const double *A, const double *B, double
         }
         return TTSK_OK;
     }
+    if (d.batch == 1 && !k_scale && d.c_n == 1) {
+        // rows of an unfolding against a DRM matrix, both contiguous along a long contracted index (the right-hand products
+        // of a dense sketch with Gaussian matrices): both operands through LDS by LDS-DMA (dense_right_pass.hip)
+        ttsk_gemm_desc n = d;
+        if (n.Ki == 1) { n.Ki = n.Ko; n.Ko = 1; n.a_ki = n.a_ko; n.b_ki = n.b_ko; }
+        else if (n.Ko > 1 && n.a_ko == n.Ki * n.a_ki && n.b_ko == n.Ki * n.b_ki) { n.Ki *= n.Ko; n.Ko = 1; }
+        if (n.Ko == 1 && n.a_ki == 1 && n.b_ki == 1 && n.N <= 48 && n.a_m >= n.Ki && n.b_n >= n.Ki) {
+            const int rs = rows_longk_try(A, n.M, n.a_m, B, (int)n.N, n.b_n, n.Ki, C, n.c_m, n.alpha, n.accumulate, stream, st);
+            if (rs < 0) return rs;
+            if (rs == 1) return TTSK_OK;
+        }
+    }
     {
         // the chain shapes (tall-skinny, K <= 128) have their own barrier-free kernels
         ttsk_gemm_desc n = d;
