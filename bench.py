@@ -64,7 +64,11 @@ def algorithmic_flops(shape, s, l, r):
     for mu in range(1, d - 1):
         a, n, b, p, q = S[mu], shape[mu], S[mu + 1], Lr[mu], Rr[mu]
         psi += min(2 * p * a * n * b + 2 * p * n * b * q, 2 * a * n * b * q + 2 * p * a * n * q)
-    return dict(left=left, right=right, omega=omega, psi=psi, total=left + right + omega + psi)
+    # what the one-call path EXECUTES: Psi_mu = T_mu R_mu reuses T_mu = L_{mu-1}^T X_mu of the left chain (the reference
+    # recomputes it, tensor_train_sketch.py:28-34): the algorithmic count minus that first product of every interior Psi
+    shared = sum(2 * Lr[mu] * S[mu] * shape[mu] * S[mu + 1] for mu in range(1, d - 1))
+    return dict(left=left, right=right, omega=omega, psi=psi, total=left + right + omega + psi,
+                executed=left + right + omega + psi - shared)
 
 
 def load_traffic(kernel_name):
@@ -426,7 +430,12 @@ def bench_c3(args, job):
                             traffic=load_traffic(classes[dom]["kernel"]),
                             algorithmic_bytes_per_launch=classes[dom].get("algorithmic_mb_per_launch", 0) * 1e6 or None,
                             avg_launch_us=classes[dom]["avg_us"], probed_mfma_f64_peak=probe.value, classes=classes,
-                            pipeline_tflops=fl["total"] * items_per_step * args.steps / elapsed * 1e-12)
+                            pipeline_tflops=fl["total"] * items_per_step * args.steps / elapsed * 1e-12,
+                            pipeline_tflops_executed=fl["executed"] * items_per_step * args.steps / elapsed * 1e-12,
+                            pipeline_frac_executed=fl["executed"] * items_per_step * args.steps / elapsed * 1e-12 / PEAK_F64_MFMA_TF,
+                            pipeline_note="pipeline_tflops counts SURVEY 8d's unfused algorithmic flops (6.017 GF per sketch); "
+                                          "_executed leaves out the first product of every interior Psi, which the one-call path "
+                                          "shares with the left chain and does not execute")
         cpu, parity = None, None
         if not args.no_cpu and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the closing barrier)
             h_cores, h_l, h_r = host_cores(tts[0]), [np.asarray(c) for c in left.cores], [np.asarray(c) for c in right.cores]

@@ -54,8 +54,16 @@ __device__ __forceinline__ void cf_barrier()
     // LDS traffic of this wave is complete, nothing moves across; vector-memory loads stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-#define CF_BARRIER() do { if (!(a.diag & 4)) cf_barrier(); } while (0)
+// Timing experiments (TTSK_CF_DIAG / TTSK_CF_STAMPS) exist in a lab build only (-DTTSK_LAB): the shipped code object carries
+// neither the run-time switches nor the stamp stores in its hot loop.
+#ifdef TTSK_LAB
+#define CF_DIAG(bit) (a.diag & (bit))
 #define CF_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && lane == 0 && k - k_beg < 8) a.stamps[((k - k_beg) * 8 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CF_DIAG(bit) 0
+#define CF_STAMP(i) do { } while (0)
+#endif
+#define CF_BARRIER() do { if (!CF_DIAG(4)) cf_barrier(); } while (0)
 
 // NQF / NNF full 16-wide tiles of a / a', STRQ / STRN 4-wide strips behind them; D ring depth of the
 // G fragments; WT: T is also written to memory; OCC workgroups per CU the register budget allows.
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
         // consecutive units.  Rows beyond A repeat row A - 1: they meet exact zeros of T.
         // (A rolled loop: unrolled, the 80 LDS destinations are hoisted into 80 scalar registers and the
         // whole kernel starts spilling them.)
-        const int NI = (a.diag & 2) ? 0 : a.eunits >> 6;
+        const int NI = CF_DIAG(2) ? 0 : a.eunits >> 6;
         const uint32_t inv = (uint32_t)(((1ull << 32) + (uint32_t)A2P - 1) / (uint32_t)A2P);   // U / A2P for U < 2^16
         const int64_t rowstride = (int64_t)a.n * a.A2;
         const int ebuf = a.eunits * 2;                 // doubles per E image
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void chain_step_kernel(ChainStep a)
     // ---- compute wave: rows j0 .. j0 + 15 of the output
     const int j0 = 16 * w;
     const bool jok = j0 + x16 < a.J;
-    const uint32_t xlane = !(a.diag & 1) ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
+    const uint32_t xlane = !CF_DIAG(1) ? (uint32_t)(((int64_t)(j0 + x16) * a.x_j + (int64_t)kq * a.x_c) * 8) : OOB_OFF;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(uniform_ptr(a.X[prob]), a.x_extent * 8);
     // wave-uniform by construction; said so explicitly, or a value the register allocator parks in a
     // vector register turns every load below into a waterfall loop

@@ -85,7 +85,9 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
     const int ebuf = nq <= 4 ? 2 : 1;
     const size_t lds = ((size_t)a.ebase + (size_t)a.eunits * 2 * ebuf) * 8;
     if (lds > 160 * 1024) return 0;
+#ifdef TTSK_LAB
     { static int dg = [] { const char *e = getenv("TTSK_CF_DIAG"); return e ? atoi(e) : 0; }(); a.diag = dg; }
+#endif
     // 32-bit byte offsets: the X walk (incl. the masked prefetch one slice past the end) and T
     if ((c.x_extent + c.x_k + 132 * c.x_c) * 8 >= (1ll << 32) - 64) return 0;
     if ((int64_t)c.A * c.n * c.A2 * 8 >= (1ll << 32) - 64) return 0;
@@ -112,7 +114,11 @@ int chain_fused_try(const ChainStepArgs &c, int stream, hipStream_t st, bool for
     // flops of BOTH products of the step (the pair this kernel replaces), reduce launch inside the bracket
     if (prof) prof_open(st, 2.0 * c.nb * (double)c.n * c.J * ((double)c.K1 * c.A + (double)c.A * c.A2), 6,
                         nq * 100 + sq * 10 + (wt ? 1 : 0), unr == 25, false);
+#ifdef TTSK_LAB
     static int stamps_on = [] { const char *e = getenv("TTSK_CF_STAMPS"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int stamps_on = 0;
+#endif
     long long *stamps_dev = nullptr;
     if (stamps_on) {
         if (hipMalloc(&stamps_dev, 8 * 8 * 8 * 8) != hipSuccess) return TTSK_ERR_HIP;

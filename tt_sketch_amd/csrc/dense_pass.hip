@@ -47,6 +47,13 @@ __device__ __forceinline__ double mfma4s(double a, double b, double c)
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// Timing experiments (TTSK_DP_DBG) exist in a lab build only (-DTTSK_LAB)
+#ifdef TTSK_LAB
+#define DP_DBG(bit) (a.dbg & (bit))
+#else
+#define DP_DBG(bit) 0
+#endif
+
 struct DensePass {
     const double *X;
     int64_t sb;            // elements between consecutive b
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     // The range is walked from a start that differs from workgroup to workgroup (the same for the nt workgroups that share
     // rows): with power-of-two extents every b row and every q range begins at the same offset modulo 2 MB.
     const int len = it_end - it_beg;
-    const int rot = len > 0 && !(a.dbg & 4) ? (int)(((uint32_t)qc * 2654435761u >> 8) % (uint32_t)len) : 0;
+    const int rot = len > 0 && !(DP_DBG(4)) ? (int)(((uint32_t)qc * 2654435761u >> 8) % (uint32_t)len) : 0;
     auto tile_of = [&](int rel) { const int t = rel + rot; return it_beg + (t >= len ? t - len : t); };
 
     if (len > 0) issue(tile_of(0), 0);
@@ -211,15 +218,15 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
             // behind the first step, so that the matrix pipes start right after the barrier, and ONE instruction per step: the
             // next tile's loads (its image was last read before that barrier) at steps 1 .. NBW, the rows of P, then the
             // previous tile's row of Z.  (TTSK_DP_DBG=8: all of them behind step 1, as one burst.)
-            if ((a.dbg & 8) ? s == 1 : (s >= 1 && s <= NBW + 2)) {
-                const bool more = rel + 1 < len && !(a.dbg & 1);
-                if (a.dbg & 8) {
+            if ((DP_DBG(8)) ? s == 1 : (s >= 1 && s <= NBW + 2)) {
+                const bool more = rel + 1 < len && !(DP_DBG(1));
+                if (DP_DBG(8)) {
                     if (more) issue(tile_of(rel + 1), buf ^ 1);
-                    if (rel > 0 && !(a.dbg & 2)) store_z(tile_of(rel - 1));
+                    if (rel > 0 && !(DP_DBG(2))) store_z(tile_of(rel - 1));
                 } else {
                     if (s <= NBW) { if (more) issue_x(next_tile, buf ^ 1, s - 1); }
                     else if (s == NBW + 1) { if (more) issue_p(next_it, buf ^ 1); }
-                    else if (rel > 0 && !(a.dbg & 2)) store_z(tile_of(rel - 1));
+                    else if (rel > 0 && !(DP_DBG(2))) store_z(tile_of(rel - 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         // the next tile has landed (and the stores are done); no fence: LDS traffic of this wave complete, then the barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (len > 0 && !(a.dbg & 2)) store_z(tile_of(len - 1));
+    if (len > 0 && !(DP_DBG(2))) store_z(tile_of(len - 1));
 
     // the accumulators as they are: [b][slot][lane], slot = 4 * tile + register, 8 + strip
     double *out = a.slab + ((int64_t)id * NB + w * NBW) * 640 + lane;
@@ -325,7 +332,11 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
         zout = (double *)scratch(stream, SCRATCH_GEMM, (size_t)nbb * zblock * 8);
         if (!zout) return TTSK_ERR_HIP;
     }
+#ifdef TTSK_LAB
     static const int dbg = [] { const char *e = getenv("TTSK_DP_DBG"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int dbg = 0;
+#endif
     DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, zout, slab, nt, (int)nqc, zblock, dbg};
     const size_t lds = (size_t)(2 * NB * 128 + 2 * DP_PBUF + NB * 20) * 8;
     static PerInit attr;
