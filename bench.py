@@ -679,9 +679,11 @@ def bench_c5(args, job):
                 dtype="f64", data="synthetic",
                 config=dict(workload="C5: stream_sketch of a TensorSum of 32 rank-20 TTs, d=6 n=128, shared TensorTrainDRMs l=50 r=100; "
                                      "terms dealt over the ranks, one all-reduce (stream_sketch_sharded)" , terms=terms),
-                roofline=dict(bound="mfma", kernel="ttsk_tt_sketch_sum of the 32 terms (two-launch chain steps merged over the terms, Psi / Omega over (term, rank))",
+                roofline=dict(bound="mfma", kernel="ttsk_tt_sketch_sum of the 32 terms: chain_sum_kernel (stacked-terms chain steps: 16-row tiles that span terms), "
+                                                   "Psi of the sum as K chunks on stream_small_kernel, the Omega of all modes in one launch",
                               achieved=gf / t_step * 1e-12, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s",
-                              frac=gf / t_step * 1e-12 / PEAK_F64_MFMA_TF, traffic=None,
+                              frac=gf / t_step * 1e-12 / PEAK_F64_MFMA_TF, traffic=load_traffic("c5_sketch"),
+                              algorithmic_bytes=(terms * 13.9e6 + 60.0e6),
                               what="algorithmic flops of the 32 term sketches (SURVEY 8d: 0.443 GF each) / wall time of one "
                                    "stream_sketch call incl. Python"),
                 cpu_baseline=cpu, **({"sketch_check": check} if check is not None else {}))

@@ -23,7 +23,7 @@ import sys
 import pandas as pd
 
 NAMES = (r"((?:gemm_f64_kernel|skinny_s_kernel|skinny_r_kernel|chain_step_kernel|chain_wide_kernel|stream_small_kernel|"
-         r"sample_rows_kernel|sample_kernel|sparse_psi_mfma_kernel|dense_pass_kernel)<[^>]*>|dense_pass_reduce|dense_pass_zsum|splitk_reduce_kernel|skinny_r_reduce2?|small_gemm_kernel|"
+         r"sample_rows_kernel|sample_kernel|sparse_psi_mfma_kernel|dense_pass_kernel|chain_sum_kernel|dense_left_pass_kernel)<[^>]*>|rows_longk_kernel|dense_pass_reduce|dense_pass_zsum|splitk_reduce_kernel|skinny_r_reduce2?|small_gemm_kernel|"
          r"sg_pass_kernel|sg_psi_reduce_kernel|sg_om_reduce_kernel|expand_rows_kernel|chol_inv_kernel|hh_sign_scale_kernel)")
 
 
@@ -51,7 +51,7 @@ if "--total" in args:
     args = args[:i] + args[i + 3:]
 fetch_c, write_c = load(args[0], "FETCH_SIZE"), load(args[1], "WRITE_SIZE")
 fetch, write = per_kernel(fetch_c), per_kernel(write_c)
-dst = args[2] if len(args) > 2 else "profiles/r03_traffic.json"
+dst = args[2] if len(args) > 2 else "profiles/r04_traffic.json"
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 for k in fetch.index:
     if k in out:
