@@ -504,6 +504,9 @@ __global__ __launch_bounds__(512, 2) void chain_sum_kernel(ChainSum a)
         if (tb == i) Wterm = a.W[i];
         if (gt == i) Xterm = a.X[i];
     }
+#ifdef TTSK_LAB
+    if (a.s.stamps && blockIdx.x == 0 && lane == 0) a.s.stamps[w * 8 + 6] = __builtin_amdgcn_s_memtime();      // kernel entry
+#endif
     CsPre<JS, KB1, NA> pre;
     cs_prologue<JS, KB1, NA, WT>(a.s, ro, Wterm, Xterm, cs_lds, g, rr, w, lane, pre);
 #define CS_CALL(RT_, CT_, SR_, NS_) cs_wave<JS, KB1, NA, WT, RT_, CT_, SR_, NS_>(a.s, ro, pre, cs_lds, g, rr, w, lane)
@@ -517,6 +520,9 @@ __global__ __launch_bounds__(512, 2) void chain_sum_kernel(ChainSum a)
 #undef CS_CALL
 #undef CS_RECT
 #undef CS_STRIP
+#ifdef TTSK_LAB
+    if (a.s.stamps && blockIdx.x == 0 && lane == 0) a.s.stamps[w * 8 + 7] = __builtin_amdgcn_s_memtime();      // behind the partial results
+#endif
 }
 
 // 1 = launched (the slab reduce included), 0 = shape not covered, < 0 = error.  T of the base arguments is ignored:

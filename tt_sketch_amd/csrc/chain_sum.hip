@@ -262,6 +262,9 @@ int chain_sum_try(const ChainSumArgs &cc, int stream, hipStream_t st, bool force
         (void)hipFree(stamps_dev);
         long long t0 = 0;
         for (int i = 0; i < 8 * 8 * 8; ++i) if (h[i] && (!t0 || h[i] < t0)) t0 = h[i];
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "[cs stamps] wave %d: kernel entry -> first slice %lld cycles, last barrier -> behind the stores %lld cycles\n", w,
+                    h[w * 8 + 0] - h[w * 8 + 6], h[w * 8 + 7] - h[(3 * 8 + w) * 8 + 5]);
         fprintf(stderr, "[cs stamps] workgroup 0, cycles since its first stamp; slice, wave (body): start | endA | dma landed | afterB1 | endB | afterB2\n");
         for (int sl = 0; sl < 4; ++sl)
             for (int w = 0; w < 8; ++w) {
