@@ -220,6 +220,9 @@ int ttsk_sparse_normal_table(const uint64_t *shape, int m, int rank_min, int ran
 int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *row_order,
                          const uint64_t *shape, int m, size_t N, int true_rank, int rank_min,
                          int rank_max, int nnz_per_row, uint64_t seed, double *dev_out, int stream);
+/* sign rows for EVERY possible prefix, as ttsk_sparse_normal_table (sparse_sign_drm.py:34-51 on all index rows at once) */
+int ttsk_sparse_sign_table(const uint64_t *shape, int m, int true_rank, int rank_min, int rank_max, int nnz_per_row, uint64_t seed,
+                           double *dev_out, int stream);
 /* counter-based N(0,1) fill for TensorTrainDRM / DenseGaussianDRM sampling
  * (tensor.py:358-371 via utils.py:178-227; dense_gaussian_drm.py:50-55): the
  * reference's streams are not reproducible across hosts, parity is by
@@ -267,17 +270,19 @@ int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const in
                             const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
                             const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream);
 /* one DRM factor of a pass: kind 0 = ones (width 1), 1 = table[flat][w] (every possible prefix sampled once:
- * ttsk_sparse_normal_table), 2 = sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c) + seed)));
+ * ttsk_sparse_normal_table / ttsk_sparse_sign_table), 2 = normals sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c)
+ * + seed))), 3 = sparse-sign rows sampled in the pass (fast_lazy_gaussian.pyx:121-180; whole row <= 32 entries);
  * flat = src 0: prefix, 1: suffix, 2: prefix + j * mul, 3: suffix + j * mul (the prefix / suffix one mode longer) */
 typedef struct {
     int kind, w, rank_min, src;
     uint64_t mul, seed;
     const double *table;
+    int full, nnz;          /* kind 3 only: length of the whole sign row, its +-1 entries (sparse_sign_drm.py:34-51) */
 } ttsk_sg_factor;
 /* Psi[a, j, c] (+)= sum_{e: j_e = j} val_e A[e, a] B[e, c]   (dev_psi (wA, n, wB), zero-initialised by the caller)
  * and, with C != NULL, Omega += sum_e val_e C[e, a] B[e, c] (c_left) or sum_e val_e A[e, a] C[e, c]  (dev_omega,
- * zero-initialised).  Stream in ascending j (ttsk_sparse_mode_stream); dev_j == NULL: one slice.  Widths <= 16.
- * No atomics: the result is bit-reproducible. */
+ * zero-initialised).  Stream in ascending j (ttsk_sparse_mode_stream); dev_j == NULL: one slice.  Widths <= 32 (one
+ * 16-column matrix tile per factor up to 16, 2 x 2 tiles per product beyond).  No atomics: the result is bit-reproducible. */
 int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
                            int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
                            double *dev_psi, double *dev_omega, int stream);

@@ -1060,6 +1060,56 @@ def test_sparse_fused_passes_vs_oracle_and_generator_path(tsa, case, monkeypatch
         assert rel(a, b) < 1e-11
 
 
+@pytest.mark.parametrize("case", [
+    # (shape, nnz, left (kind, true rank, lo, hi, non-zeros per row), right (...)); "g" = SparseGaussianDRM, "s" = SparseSignDRM
+    ((40, 30, 20, 25, 35), 20000, ("g", 24, 0, 24, None), ("g", 24, 0, 24, None)),        # two 16-column tiles per factor
+    ((200, 150, 100, 120, 300), 60000, ("g", 17, 0, 17, None), ("g", 32, 0, 32, None)),   # just outside the old cover; sampled in the pass
+    ((200, 150, 100, 120, 300), 60000, ("s", 24, 0, 24, None), ("s", 24, 0, 24, 5)),      # sign rows made in the pass (deep modes) and tables
+    ((7, 6, 5, 8), 300, ("s", 10, 0, 10, 3), ("s", 15, 0, 15, None)),                     # every sign factor a table
+    ((300, 7, 250, 9), 9000, ("s", 16, 3, 11, 9), ("g", 13, 2, 15, None)),                # a slice of a sign row; mixed pair
+    ((300, 7, 250, 9), 9000, ("g", 20, 1, 21, None), ("s", 32, 5, 30, 32)),               # mixed pair, wide
+    ((9, 11), 60, ("s", 4, 0, 4, 1), ("s", 32, 0, 32, 7)),
+])
+def test_sparse_fused_wide_and_sign_factors_vs_oracle(tsa, case, monkeypatch):
+    """the one-pass-per-mode sparse sketch beyond 16 columns per factor (2 x 2 matrix tiles) and with
+    SparseSignDRM factors (sparse_sign_drm.py:34-51: gathered from a per-prefix table or made in the pass), in every pairing
+    with SparseGaussianDRM -- against the oracle, the generator path, and itself (bit-reproducible)."""
+    shape, nnz, lspec, rspec = case
+    d = len(shape)
+    rng = np.random.default_rng(nnz + 1)
+    idx = np.stack([rng.integers(0, n, nnz) for n in shape]).astype(np.int64)
+    val = rng.standard_normal(nnz)
+
+    def mk(spec, transpose, seed):
+        kind, tr, lo, hi, nz = spec
+        t = lambda v: (v,) * (d - 1)
+        if kind == "g":
+            return (tsa.SparseGaussianDRM(t(hi), shape, transpose, seed=seed, rank_min=t(lo), rank_max=t(hi), true_rank=t(hi)),
+                    orc.HashGaussDrm(seed, shape, transpose, t(lo), t(hi)))
+        return (tsa.SparseSignDRM(t(tr), shape, transpose, seed=seed, rank_min=t(lo), rank_max=t(hi), true_rank=t(tr),
+                                  num_non_zero_per_row=None if nz is None else t(nz)),
+                orc.HashSignDrm(seed, shape, transpose, t(tr), t(lo), t(hi), None if nz is None else t(nz)))
+
+    (ld, old), (rd, ord_) = mk(lspec, False, 3), mk(rspec, True, 4)
+    T = tsa.SparseTensor(shape, idx, val)
+    from tt_sketch_amd import sparse_fused
+    assert sparse_fused.try_sparse_gauss_sketch(T, ld, rd, tsa.SketchMethod.streaming) is not None
+    sk = tsa.general_sketch(T, ld, rd, tsa.SketchMethod.streaming)
+    oP, oO = orc.general_sketch("sparse", (shape, idx, val), old, ord_, "streaming")
+    got = sk.Psi_cores + sk.Omega_mats
+    for a, b in zip(got, oP + oO):
+        assert a.shape == b.shape and rel(a, b) < 1e-11, (a.shape, rel(a, b))
+    again = tsa.general_sketch(tsa.SparseTensor(shape, idx, val), mk(lspec, False, 3)[0], mk(rspec, True, 4)[0],
+                               tsa.SketchMethod.streaming)
+    for a, b in zip(got, again.Psi_cores + again.Omega_mats):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("TTSK_SPARSE_FUSED", "0")
+    gen = tsa.general_sketch(tsa.SparseTensor(shape, idx, val), mk(lspec, False, 3)[0], mk(rspec, True, 4)[0],
+                             tsa.SketchMethod.streaming)
+    for a, b in zip(got, gen.Psi_cores + gen.Omega_mats):
+        assert rel(a, b) < 1e-11
+
+
 def test_sparse_fused_samples_are_bit_identical_to_the_sampler(tsa):
     """One nonzero per first-mode slice with entry 1: Psi_0[0, j, :] IS the right DRM row of that nonzero -- the
     samples made inside the pass (table and in-pass kinds) against ttsk_inds_to_normal, bit for bit."""

@@ -141,7 +141,7 @@ __global__ void sign_kernel(const int64_t *__restrict__ idx, IndexMap im, size_t
 {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
-    const uint64_t flat = flat_index(idx, im, e);
+    const uint64_t flat = idx ? flat_index(idx, im, e) : (uint64_t)e;   // no index rows: row e IS the flat index
     for (int j = 0; j < rank; ++j) ws[(size_t)j * N + e] = 0;
     for (int j = 0; j < nnz; ++j) {
         uint64_t bits = rand_bits(flat, j, seed);
@@ -460,6 +460,23 @@ int ttsk_sparse_sign_dev(const int64_t *dev_idx, int64_t row_stride, const int *
     int rc = make_index_map(shape, m, row_stride, row_order, &im);
     if (rc) return rc;
     return sign_dev<double>(dev_idx, im, N, true_rank, rank_min, rank_max, nnz_per_row, seed, dev_out, st, stream);
+}
+
+int ttsk_sparse_sign_table(const uint64_t *shape, int m, int true_rank, int rank_min, int rank_max, int nnz_per_row, uint64_t seed,
+                           double *dev_out, int stream)
+{
+    TTSK_STREAM(st, stream);
+    TTSK_ARG(shape && dev_out, "ttsk_sparse_sign_table: NULL argument");
+    IndexMap im;
+    int rc = make_index_map(shape, m, 0, nullptr, &im);
+    if (rc) return rc;
+    double prod = 1.0;
+    for (int i = 0; i < m; ++i) prod *= (double)shape[i];
+    if (!(prod < 2147483648.0)) {
+        set_error("ttsk_sparse_sign_table: %g prefixes: the reference's 32-bit running product wraps", prod);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    return sign_dev<double>(nullptr, im, (size_t)prod, true_rank, rank_min, rank_max, nnz_per_row, seed, dev_out, st, stream);
 }
 
 static int host_sample(const void *host_idx, const uint64_t *shape, int m, size_t N, int rank_min,

@@ -27,12 +27,13 @@
 namespace ttsk {
 
 struct SgF {
-    int kind;            // 0: ones (width 1), 1: table gathered by flat index, 2: sampled in the pass
-    int w;               // columns (<= 16)
+    int kind;            // 0: ones (width 1), 1: table gathered by flat index, 2: normals sampled in the pass, 3: sign rows sampled in the pass
+    int w;               // columns of the factor (<= 16 NT)
     int rank_min;
     int src;             // flat index: 0 = prefix, 1 = suffix, 2 = prefix + j * mul, 3 = suffix + j * mul
     uint64_t mul, seed;
     const double *table;
+    int full, nnz;       // kind 3: length of the whole DRM row ([rank_min, rank_min + w) of it is used), its +-1 entries
 };
 
 struct SgPass {
@@ -43,7 +44,8 @@ struct SgPass {
     int64_t n;           // slices of Psi
     SgF f[3];            // Psi = (val A) (x) B by slice; Omega = (val C) (x) B  (c_left)  or  (val A) (x) C
     int c_left, has_om;
-    int off[3], tcols;   // column offsets of the factors in the staged tile, its row length
+    int off[3], tcols;   // sampled factor: column offset in the staged tile (of what the products read), the tile's row length;
+    int tab;             // table factor: offset of its block [w][SG_TP] behind the tile; doubles of all table blocks
     int qcols;           // columns of the sampled factors: the tail queue holds at most SG_T * qcols slots
     double *psi;         // [wA][n][wB]
     double *part_psi;    // [wave][2][wA * wB]
@@ -52,6 +54,7 @@ struct SgPass {
 };
 
 constexpr int SG_T = 32;         // nonzeros per staged tile
+constexpr int SG_TP = SG_T + 1;  // pitch of a table block's columns (the products read 16 columns at one nonzero: distinct banks)
 
 // ndtri as a CALL in this kernel: inlined at its two sites it takes the pass kernel to ~230 VGPRs (two waves per SIMD,
 // or 49 spilled registers under a tighter cap); the call costs a few scalar instructions per ~100 of arithmetic.
@@ -63,22 +66,32 @@ __device__ __forceinline__ uint64_t sg_flat(const SgF &f, uint64_t fl, uint64_t 
     return (f.src & 2) ? base + (uint64_t)(int64_t)j * f.mul : base;
 }
 
-__global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
+__host__ __device__ inline size_t sg_per_wave(int tcols, int tab, int qcols)
+{
+    return (size_t)SG_T * tcols + tab + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * qcols + 3) / 4;
+}
+
+// NT: 16-column matrix tiles per factor.  NT = 1 (every factor <= 16 columns: C4) is the round-3 kernel; NT = 2 takes
+// factors of up to 32 columns with 2 x 2 accumulator tiles per product (two waves per SIMD: 64 accumulator registers).
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 {
     extern __shared__ double sg_lds[];
-    __shared__ uint64_t salt[3][16];
+    __shared__ uint64_t salt[3][16 * NT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x16 = lane & 15, kq = lane >> 4;
-    if (tid < 48) {
-        const int f = tid >> 4, c = tid & 15;
-        salt[f][c] = mix64((uint64_t)(a.f[f].rank_min + c)) + a.f[f].seed;
+    if (tid < 48 * NT) {
+        const int f = tid / (16 * NT), c = tid % (16 * NT);
+        salt[f][c] = mix64((uint64_t)((a.f[f].kind == 3 ? 0 : a.f[f].rank_min) + c)) + a.f[f].seed;
     }
     __syncthreads();                                   // the only workgroup barrier: waves run free from here
     const int tcols = a.tcols;
-    // per-wave LDS: tile[SG_T][tcols] | fl[SG_T] | fr[SG_T] | val[SG_T] | j[SG_T] (int) | queue (ushort, SG_T * qcols)
-    const size_t per_wave = (size_t)SG_T * tcols + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * a.qcols + 3) / 4;
+    // per-wave LDS: tile[SG_T][tcols] (the sampled factors) | table blocks [w][SG_TP] | fl[SG_T] | fr[SG_T] | val[SG_T] | j[SG_T] (int) |
+    // queue (ushort, SG_T * qcols)
+    const size_t per_wave = sg_per_wave(tcols, a.tab, a.qcols);
     double *tile = sg_lds + (size_t)wv * per_wave;
-    uint64_t *rfl = (uint64_t *)(tile + SG_T * tcols), *rfr = rfl + SG_T;
+    double *tabs = tile + SG_T * tcols;
+    uint64_t *rfl = (uint64_t *)(tabs + a.tab), *rfr = rfl + SG_T;
     double *rv = (double *)(rfr + SG_T);
     int *rj = (int *)(rv + SG_T);
     unsigned short *q = (unsigned short *)(rj + SG_T);
@@ -96,7 +109,14 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
     }
     const size_t end = beg + a.chunk < a.N ? beg + a.chunk : a.N;
     const int jfirst = a.jj ? a.jj[beg] : 0;
-    v4d accP = {0.0, 0.0, 0.0, 0.0}, accO = {0.0, 0.0, 0.0, 0.0};
+    v4d accP[NT][NT], accO[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            accP[i][k] = v4d{0.0, 0.0, 0.0, 0.0};
+            accO[i][k] = v4d{0.0, 0.0, 0.0, 0.0};
+        }
     int cur = jfirst;
     bool first_done = false;
 
@@ -117,11 +137,15 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
             stride_a = (int64_t)a.n * wB;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int aa = 4 * t + kq;
-            if (aa < wA && x16 < wB) dst[aa * stride_a + x16] = accP[t];
-            accP[t] = 0.0;
-        }
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int aa = 16 * ta + 4 * t + kq, cc = 16 * tb + x16;
+                    if (aa < wA && cc < wB) dst[aa * stride_a + cc] = accP[ta][tb][t];
+                    accP[ta][tb][t] = 0.0;
+                }
     };
     if (lane == 0) { pj[0] = jfirst; pj[1] = jfirst; pj[2] = 0; }
 
@@ -151,7 +175,25 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
         }
         rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
         __builtin_amdgcn_wave_barrier();
-        // ---- (2) the factors into the tile
+        // ---- (2a) the table factors: row flat[t] of the table to column-major blocks [c][SG_TP] by LDS-DMA (lane = (nonzero
+        // lane >> 1, dword lane & 1); one instruction per column moves 32 doubles), no registers held: the rows of ALL table
+        // factors travel while the sampled factors are evaluated, and are waited for once, in front of the products
+        // (the register gather of rounds 3-4 paid one round trip per table factor: 0.6 ms per pass at C4)
+#pragma unroll 1
+        for (int f = 0; f < 3; ++f) {
+            const SgF &F = a.f[f];
+            if (F.kind != 1) continue;
+            const int t = lane >> 1;
+            const int jt = rj[t];
+            const uint64_t flat = jt >= 0 ? sg_flat(F, rfl[t], rfr[t], jt) : 0;
+            const char *src = (const char *)(F.table + flat * (uint64_t)F.w) + 4 * (lane & 1);
+            double *blk = tabs + a.off[f];
+#pragma unroll 1
+            for (int c = 0; c < F.w; ++c)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 8 * c),
+                                                 (__attribute__((address_space(3))) void *)(blk + c * SG_TP), 4, 0, 0);
+        }
+        // ---- (2b) the sampled factors into the tile
         int qn = 0;
 #pragma unroll 1
         for (int f = 0; f < 3; ++f) {
@@ -161,14 +203,14 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
                 for (int ci = 0; 2 * ci < F.w; ++ci) {          // the same trip count in both halves: the ballots below are wave-wide
                     const int c = 2 * ci + half;
                     const bool act = valid && c < F.w;
-                    const uint64_t h = mix64(flat + salt[f][c & 15]);
+                    const uint64_t h = mix64(flat + salt[f][c & (16 * NT - 1)]);
                     const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
                     const double u = mant_unit(bits);
                     const double expm2 = 0.13533528323661269189;
                     const int slot = t32 * tcols + a.off[f] + c;
                     const bool central = u > expm2 && u <= 1.0 - expm2;
                     const bool tail = act && !central;
-                    if (act && central) tile[slot] = sg_ndtri(u);
+                    if (act && central) tile[slot] = ndtri_central_dev(u);      // inline: no call (and no wait for the DMA) in this stage
                     const unsigned long long m = __ballot(tail);
                     if (tail) {
                         tile[slot] = u;
@@ -176,18 +218,32 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
                     }
                     qn += __popcll(m);
                 }
-            } else if (F.kind == 1) {
-                // table rows: lane (row group lane >> 4, column x16); all eight loads in flight before the first store
-                double g[SG_T / 4];
-#pragma unroll
-                for (int i = 0; i < SG_T / 4; ++i) {
-                    const int t = 4 * i + kq;
-                    const uint64_t flat = sg_flat(F, rfl[t], rfr[t], rj[t]);
-                    g[i] = (x16 < F.w && rj[t] >= 0) ? F.table[flat * (uint64_t)F.w + x16] : 0.0;
+            } else if (F.kind == 3) {
+                // a sparse-sign row (fast_lazy_gaussian.pyx:121-180, as sign_kernel of sampler.hip): +-1 at the first nnz
+                // positions of a row of `full` zeros, then nnz swaps in order.  The whole row lives in the tile, at columns
+                // off - rank_min ..; the products read [off, off + w).  Signs by both halves, the swaps by one lane per nonzero.
+                const uint64_t flat = sg_flat(F, my_fl, my_fr, my_j);
+                double *row = tile + t32 * tcols + (a.off[f] - F.rank_min);
+                for (int c = half; c < F.full; c += 2) {
+                    double s = 0.0;
+                    if (c < F.nnz) {
+                        const uint64_t h = mix64(flat + salt[f][c]);
+                        const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
+                        const int ex = (int)((bits >> 52) & 0x7FF) - 1022;
+                        s = (double)((((ex % 2) + 2) % 2) * 2 - 1);
+                    }
+                    row[c] = s;
                 }
-#pragma unroll
-                for (int i = 0; i < SG_T / 4; ++i)
-                    if (x16 < F.w) tile[(4 * i + kq) * tcols + a.off[f] + x16] = g[i];
+                __builtin_amdgcn_wave_barrier();
+                if (half == 0)
+                    for (int c = 0; c < F.nnz; ++c) {
+                        const uint64_t h = mix64(flat + salt[f][c]);
+                        const double u = mant_unit((h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL);
+                        const int pick = (int)(u * (double)(F.full - c) + (double)c);
+                        const double x = row[c], y = row[pick];
+                        row[c] = y;
+                        row[pick] = x;
+                    }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -198,24 +254,47 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
                 tile[slot] = sg_ndtri(tile[slot]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the table blocks have landed
         __builtin_amdgcn_wave_barrier();
         // ---- (4) the products: k-block b = nonzeros 4 b .. 4 b + 3 of the tile
+        // element (nonzero e, column c) of factor i: a table block is [c][SG_TP], a sampled factor [e][tcols]
+        const int sc0 = a.f[0].kind == 1 ? SG_TP : 1, sc1 = a.f[1].kind == 1 ? SG_TP : 1, sc2 = a.f[2].kind == 1 ? SG_TP : 1;
+        const int se0 = a.f[0].kind == 1 ? 1 : tcols, se1 = a.f[1].kind == 1 ? 1 : tcols, se2 = a.f[2].kind == 1 ? 1 : tcols;
+        const double *p0 = (a.f[0].kind == 1 ? tabs : tile) + a.off[0] + kq * se0 + x16 * sc0;
+        const double *p1 = (a.f[1].kind == 1 ? tabs : tile) + a.off[1] + kq * se1 + x16 * sc1;
+        const double *p2 = (a.f[2].kind == 1 ? tabs : tile) + a.off[2] + kq * se2 + x16 * sc2;
 #pragma unroll 2
         for (int b = 0; b < SG_T / 4; ++b) {
             const int e = 4 * b + kq;
             const int je = rj[e];
             const bool ok = je >= 0;
             const double v = rv[e];
-            const double *row = tile + e * tcols;
-            double av = a.f[0].kind ? (ok && x16 < wA ? row[a.off[0] + x16] : 0.0) : (x16 == 0 ? 1.0 : 0.0);
-            const double bv = a.f[1].kind ? (ok && x16 < wB ? row[a.off[1] + x16] : 0.0) : (x16 == 0 ? 1.0 : 0.0);
-            av *= v;
+            double av[NT], bv[NT], cv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 16 * t + x16;
+                av[t] = a.f[0].kind ? (ok && c < wA ? p0[4 * b * se0 + 16 * t * sc0] : 0.0) : (c == 0 ? 1.0 : 0.0);
+                bv[t] = a.f[1].kind ? (ok && c < wB ? p1[4 * b * se1 + 16 * t * sc1] : 0.0) : (c == 0 ? 1.0 : 0.0);
+                av[t] *= v;
+                cv[t] = 0.0;
+            }
             if (a.has_om) {
-                const double cv = (ok && x16 < a.f[2].w) ? row[a.off[2] + x16] : 0.0;
-                accO = a.c_left ? mfma16(cv * v, bv, accO) : mfma16(av, cv, accO);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = 16 * t + x16;
+                    cv[t] = (ok && c < a.f[2].w) ? p2[4 * b * se2 + 16 * t * sc2] : 0.0;
+                }
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb)
+                        accO[ta][tb] = a.c_left ? mfma16(cv[ta] * v, bv[tb], accO[ta][tb]) : mfma16(av[ta], cv[tb], accO[ta][tb]);
             }
             if (__ballot(ok && je != cur) == 0ull) {
-                accP = mfma16(av, bv, accP);
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
             } else {
                 for (int qq = 0; qq < 4; ++qq) {
                     const int okq = __shfl((int)ok, 16 * qq);
@@ -225,7 +304,10 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
                         flush(cur, false);
                         cur = jq;
                     }
-                    accP = mfma16(kq == qq ? av : 0.0, bv, accP);
+#pragma unroll
+                    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(kq == qq ? av[ta] : 0.0, bv[tb], accP[ta][tb]);
                 }
             }
         }
@@ -235,10 +317,14 @@ __global__ __launch_bounds__(256, 3) void sg_pass_kernel(SgPass a)
     if (a.has_om) {
         double *dst = a.part_om + w_id * (size_t)(wOl * wOr);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int aa = 4 * t + kq;
-            if (aa < wOl && x16 < wOr) dst[aa * wOr + x16] = accO[t];
-        }
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int aa = 16 * ta + 4 * t + kq, cc = 16 * tb + x16;
+                    if (aa < wOl && cc < wOr) dst[aa * wOr + cc] = accO[ta][tb][t];
+                }
     }
 }
 
@@ -394,30 +480,54 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     SgPass a{};
     a.fl = dev_fl; a.fr = dev_fr; a.jj = dev_j; a.val = dev_val; a.N = N; a.n = n;
     const ttsk_sg_factor *fs[3] = {A, B, C};
-    int cols = 0;
+    int cols = 0, widest = 1;
     for (int i = 0; i < 3; ++i) {
         SgF &F = a.f[i];
         if (!fs[i]) { F.kind = 0; F.w = 1; continue; }
         F.kind = fs[i]->kind; F.w = fs[i]->kind ? fs[i]->w : 1; F.rank_min = fs[i]->rank_min; F.src = fs[i]->src;
         F.mul = fs[i]->mul; F.seed = fs[i]->seed; F.table = fs[i]->table;
-        TTSK_ARG(F.kind >= 0 && F.kind <= 2 && F.w >= 1 && F.w <= 16, "ttsk_sparse_gauss_pass: factor %d: kind %d, width %d", i, F.kind, F.w);
+        F.full = fs[i]->full; F.nnz = fs[i]->nnz;
+        TTSK_ARG(F.kind >= 0 && F.kind <= 3 && F.w >= 1 && F.w <= 32, "ttsk_sparse_gauss_pass: factor %d: kind %d, width %d", i, F.kind, F.w);
         TTSK_ARG(F.kind != 1 || F.table, "ttsk_sparse_gauss_pass: table factor without a table");
+        TTSK_ARG(F.kind != 3 || (F.full >= 1 && F.full <= 32 && F.nnz >= 0 && F.nnz <= F.full && F.rank_min >= 0 && F.rank_min + F.w <= F.full),
+                 "ttsk_sparse_gauss_pass: factor %d: sign row of %d entries, %d non-zero, columns [%d, %d)", i, F.full, F.nnz, F.rank_min,
+                 F.rank_min + F.w);
         TTSK_ARG(!((F.src & 1) ? !dev_fr : !dev_fl) || F.kind == 0, "ttsk_sparse_gauss_pass: factor %d needs a flat index stream", i);
-        a.off[i] = cols;
-        if (F.kind) cols += F.w;
-        if (F.kind == 2) a.qcols += F.w;
+        if (F.kind == 3) {                             // the whole row is staged; the products read its slice
+            a.off[i] = cols + F.rank_min;
+            cols += F.full;
+            if (F.full > widest) widest = F.full;
+        } else if (F.kind == 2) {
+            a.off[i] = cols;
+            cols += F.w;
+            a.qcols += F.w;
+        } else if (F.kind == 1) {                      // a block of its own behind the tile
+            a.off[i] = a.tab;
+            a.tab += F.w * SG_TP;
+        }
+        if (F.w > widest) widest = F.w;
     }
+    const int NT = widest > 16 ? 2 : 1;
     a.has_om = C != nullptr;
     a.c_left = c_left;
     a.tcols = cols > 0 ? cols : 1;
     a.psi = dev_psi;
-    // waves: what is resident at once (3 workgroups of 4 waves per CU: 141 VGPRs, <= 53 KB of LDS each), so that the
-    // grid is one even round; stretches of whole tiles
-    static const size_t resident = [] {
+    // waves: what is resident at once (NT = 1: 3 workgroups of 4 waves per CU -- 141 VGPRs, <= 53 KB of LDS each; NT = 2: two
+    // by the registers, fewer by the LDS of wide tiles), so that the grid is one even round; stretches of whole tiles
+    static const size_t n_cu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return (size_t)v * 12;
+        return (size_t)v;
     }();
+    const size_t per_wave = sg_per_wave(a.tcols, a.tab, a.qcols);
+    const size_t lds = per_wave * 4 * 8;
+    size_t wg_per_cu = (size_t)(156 * 1024) / (lds + 16 * NT * 24 + 64);
+    if (wg_per_cu > (NT == 1 ? 3u : 2u)) wg_per_cu = NT == 1 ? 3 : 2;
+    if (wg_per_cu < 1) {
+        set_error("ttsk_sparse_gauss_pass: a staged tile of %d columns does not fit the LDS", a.tcols);
+        return TTSK_ERR_UNSUPPORTED;
+    }
+    const size_t resident = n_cu * 4 * wg_per_cu;
     size_t waves = resident;
     size_t chunk = ((N + waves - 1) / waves + SG_T - 1) / SG_T * SG_T;
     if (chunk < 8 * SG_T) chunk = 8 * SG_T;
@@ -432,15 +542,15 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     a.part_psi = (double *)ws;
     a.part_om = a.part_psi + wtot * 2 * cellsP;
     a.part_j = (int *)(a.part_om + wtot * (size_t)cellsO);
-    const size_t per_wave = (size_t)SG_T * a.tcols + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * a.qcols + 3) / 4;
-    const size_t lds = per_wave * 4 * 8;
     static PerInit attr;
     if (attr.first()) {
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     }
     const bool prof = prof_on();
     if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");
-    hipLaunchKernelGGL(sg_pass_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (NT == 1) hipLaunchKernelGGL(sg_pass_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(sg_pass_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     TTSK_LAUNCH_CHECK();
     const int64_t rb = n < 4096 ? n : 4096;
     hipLaunchKernelGGL(sg_psi_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, a.part_psi, a.part_j, (int)wtot, wA, wB, n, dev_psi);

@@ -1,10 +1,11 @@
-"""Fast path: SparseTensor input with SparseGaussianDRMs on both sides, streaming method.
+"""Fast path: SparseTensor input with hashed sparse DRMs (SparseGaussianDRM / SparseSignDRM, any pair) on both sides,
+streaming method.
 
 One pass per mode over a resident, mode-ordered stream of the nonzeros (``csrc/sparse_fused.hip``): the DRM rows are
 sampled (or gathered from a small per-prefix table) where they are consumed, Psi_mu and one Omega come out of the
 same pass, nothing of size nnz x rank is ever written.  Numerically the same sums as
-``SparseGaussianDRM.sketch_sparse`` + ``sketch_omega_sparse`` / ``sketch_psi_sparse`` (reference
-sparse_gaussian_drm.py:29-44, sparse_sketch.py:8-69) with bit-identical samples; the summation order is fixed
+``SparseGaussianDRM.sketch_sparse`` / ``SparseSignDRM.sketch_sparse`` + ``sketch_omega_sparse`` / ``sketch_psi_sparse``
+(reference sparse_gaussian_drm.py:29-44, sparse_sign_drm.py:34-51, sparse_sketch.py:8-69) with bit-identical samples; the summation order is fixed
 (no atomics), so two runs agree bit for bit.
 """
 from __future__ import annotations
@@ -18,17 +19,19 @@ import numpy as np
 from . import _native as nat
 from .device import DevArray, axpby
 from .drm.sparse_gaussian_drm import SparseGaussianDRM
+from .drm.sparse_sign_drm import SparseSignDRM
 from .tensor import SparseTensor, TensorSum
 
 last_plan: dict = {}             # what the last sketch did (bench.py reads it): sampled columns per nonzero, table rows
-MAX_WIDTH = 16                   # columns per DRM factor the pass kernel holds in one matrix tile
+MAX_WIDTH = 32                   # columns per DRM factor the pass kernel takes (one 16-column matrix tile, or two)
 MAX_MODE = 1 << 24               # the mode-order sort key holds the mode index in 24 bits (ttsk_sparse_mode_order)
 TABLE_BYTES = 32 << 20           # a per-prefix table larger than this is sampled per nonzero instead (it would leave the L2 / MALL)
 
 
 class _Factor(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("w", ctypes.c_int), ("rank_min", ctypes.c_int), ("src", ctypes.c_int),
-                ("mul", ctypes.c_uint64), ("seed", ctypes.c_uint64), ("table", ctypes.c_void_p)]
+                ("mul", ctypes.c_uint64), ("seed", ctypes.c_uint64), ("table", ctypes.c_void_p),
+                ("full", ctypes.c_int), ("nnz", ctypes.c_int)]
 
 
 def _u64(vals):
@@ -44,8 +47,9 @@ def _flat_mult(shape) -> List[int]:
 class _Side:
     """One DRM as the passes see it: factor k = the DRM's k-th sketching matrix (k + 1 index rows)."""
 
-    def __init__(self, drm: SparseGaussianDRM, shape: Tuple[int, ...], nnz: int):
+    def __init__(self, drm, shape: Tuple[int, ...], nnz: int):
         self.drm = drm
+        self.sign = type(drm) is SparseSignDRM
         self.shape = tuple(int(n) for n in shape)          # in the order the DRM walks the tensor
         self.nnz = nnz
         self.cache = drm.__dict__.setdefault("_sg_tables", {})
@@ -53,8 +57,13 @@ class _Side:
     def width(self, k: int) -> int:
         return int(self.drm.rank_max[k] - self.drm.rank_min[k])
 
+    def staged(self, k: int) -> int:
+        """columns of the staged tile a factor sampled in the pass needs: a sign row is made whole (its swaps reach
+        every position), a Gaussian row only where it is used"""
+        return int(self.drm.true_rank[k]) if self.sign else self.width(k)
+
     def seed(self, k: int) -> int:
-        return (k + int(self.drm.seed)) % 2**63            # sparse_gaussian_drm.py:34-36
+        return (k + int(self.drm.seed)) % 2**63            # sparse_gaussian_drm.py:34-36, sparse_sign_drm.py:39-41
 
     def prefixes(self, k: int) -> int:
         return int(np.prod([int(n) for n in self.shape[:k + 1]], dtype=object))
@@ -64,22 +73,38 @@ class _Side:
         return P < 2**31 and 2 * P <= self.nnz and P * self.width(k) * 8 <= TABLE_BYTES
 
     def table(self, k: int) -> DevArray:
-        key = (k, self.shape[:k + 1], int(self.drm.rank_min[k]), int(self.drm.rank_max[k]), int(self.drm.seed))
+        drm = self.drm
+        key = (k, self.shape[:k + 1], int(drm.rank_min[k]), int(drm.rank_max[k]), int(drm.seed))
+        if self.sign:
+            key += (int(drm.true_rank[k]), int(drm.nnz[k]))
         if key not in self.cache:
             out = DevArray.empty((self.prefixes(k), self.width(k)))
-            nat.call("ttsk_sparse_normal_table", _u64(self.shape[:k + 1]), k + 1, int(self.drm.rank_min[k]),
-                     int(self.drm.rank_max[k]), ctypes.c_uint64(self.seed(k)), ctypes.c_void_p(out.ptr), 0)
+            if self.sign:
+                nat.call("ttsk_sparse_sign_table", _u64(self.shape[:k + 1]), k + 1, int(drm.true_rank[k]), int(drm.rank_min[k]),
+                         int(drm.rank_max[k]), int(drm.nnz[k]), ctypes.c_uint64(self.seed(k)), ctypes.c_void_p(out.ptr), 0)
+            else:
+                nat.call("ttsk_sparse_normal_table", _u64(self.shape[:k + 1]), k + 1, int(drm.rank_min[k]),
+                         int(drm.rank_max[k]), ctypes.c_uint64(self.seed(k)), ctypes.c_void_p(out.ptr), 0)
             self.cache[key] = out
         return self.cache[key]
 
     def factor(self, k: int, src: int, mul: int = 0) -> Tuple[_Factor, Optional[DevArray]]:
         tab = self.table(k) if self.use_table(k) else None
-        f = _Factor(1 if tab is not None else 2, self.width(k), int(self.drm.rank_min[k]), src, mul, self.seed(k),
-                    tab.ptr if tab is not None else None)
+        kind = 1 if tab is not None else (3 if self.sign else 2)
+        f = _Factor(kind, self.width(k), int(self.drm.rank_min[k]), src, mul, self.seed(k),
+                    tab.ptr if tab is not None else None,
+                    int(self.drm.true_rank[k]) if self.sign else 0, int(self.drm.nnz[k]) if self.sign else 0)
         return f, tab
 
     def cost(self, k: int) -> int:
         return 0 if self.use_table(k) else self.width(k)
+
+    def covered(self, k: int) -> bool:
+        if not 1 <= self.width(k) <= MAX_WIDTH:
+            return False
+        if self.sign and not self.use_table(k):
+            return self.staged(k) <= MAX_WIDTH and 0 <= int(self.drm.nnz[k]) <= int(self.drm.true_rank[k])
+        return True
 
 
 def _mode_stream(tensor: SparseTensor, mu: int):
@@ -115,7 +140,7 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
     from .sketch_dispatch import SketchMethod
     if method != SketchMethod.streaming or os.environ.get("TTSK_SPARSE_FUSED", "1") == "0":
         return None
-    if type(left_drm) is not SparseGaussianDRM or type(right_drm) is not SparseGaussianDRM:
+    if type(left_drm) not in (SparseGaussianDRM, SparseSignDRM) or type(right_drm) not in (SparseGaussianDRM, SparseSignDRM):
         return None
     if type(tensor) is TensorSum and tensor.tensors and all(type(t) is SparseTensor for t in tensor.tensors):
         # a sum of sparse tensors (the nnz shards of distributed.shard_tensor, reference tensor.py:215-234): every summand
@@ -143,7 +168,7 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
         raise ValueError(f"Shape {left_drm.shape} of DRM doesn't match tensor's shape {tensor.shape}")
     L = _Side(left_drm, shape, N)
     R = _Side(right_drm, shape[::-1], N)          # factor nu of the right DRM = suffix of d - 1 - nu.. = R_mu with mu = d - 2 - nu
-    if any(not 1 <= L.width(k) <= MAX_WIDTH or not 1 <= R.width(k) <= MAX_WIDTH for k in range(d - 1)):
+    if any(not L.covered(k) or not R.covered(k) for k in range(d - 1)):
         return None
     tensor.prepare_device()
     multL, multR = _flat_mult(shape), _flat_mult(shape[::-1])
@@ -184,7 +209,7 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
                 C, t = R.factor(d - 2 - k, 3, multR[d - 2 - k])
             keep.append(t)
         for f in (A, B, C):
-            if f is not None and f.kind == 2:
+            if f is not None and f.kind >= 2:
                 sampled += f.w
         P = ctypes.c_void_p
         ref = lambda f: None if f is None else ctypes.byref(f)
