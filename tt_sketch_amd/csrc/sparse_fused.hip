@@ -21,6 +21,7 @@
 //   * NO atomics: a wave stores the slices that lie inside its stretch, its first and last (shared) slices go to
 //     per-wave partial blocks that a second kernel adds in wave order -- the sketch is bit-reproducible.
 #include <cstdlib>
+#include <type_traits>
 #include <hipcub/hipcub.hpp>
 #include "sampler_dev.h"
 
@@ -51,6 +52,9 @@ struct SgPass {
     double *part_psi;    // [wave][2][wA * wB]
     int *part_j;         // [wave][3]: first slice, last slice (= first if none), 1 if the last partial exists
     double *part_om;     // [wave][wOl * wOr]
+#ifdef TTSK_LAB
+    int lab;             // TTSK_SG_LAB: 1 = no table DMA, 2 = no products, 4 = no sampling (timing experiments; results are wrong)
+#endif
 };
 
 constexpr int SG_T = 32;         // nonzeros per staged tile
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             rv[lane] = nx_v;
             rj[lane] = my_j;
         }
+        const unsigned vbits = (unsigned)__ballot(valid);                           // bit e: nonzero e of the tile exists
+        const bool tile_one_slice = __ballot(valid && my_j != cur) == 0ull;
         rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
         __builtin_amdgcn_wave_barrier();
         // ---- (2a) the table factors: row flat[t] of the table to column-major blocks [c][SG_TP] by LDS-DMA (lane = (nonzero
@@ -183,6 +189,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         for (int f = 0; f < 3; ++f) {
             const SgF &F = a.f[f];
             if (F.kind != 1) continue;
+#ifdef TTSK_LAB
+            if (a.lab & 1) continue;
+#endif
             const int t = lane >> 1;
             const int jt = rj[t];
             const uint64_t flat = jt >= 0 ? sg_flat(F, rfl[t], rfr[t], jt) : 0;
@@ -198,6 +207,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #pragma unroll 1
         for (int f = 0; f < 3; ++f) {
             const SgF &F = a.f[f];
+#ifdef TTSK_LAB
+            if (a.lab & 4) continue;
+#endif
             if (F.kind == 2) {
                 const uint64_t flat = sg_flat(F, my_fl, my_fr, my_j);
                 for (int ci = 0; 2 * ci < F.w; ++ci) {          // the same trip count in both halves: the ballots below are wave-wide
@@ -263,51 +275,79 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         const double *p0 = (a.f[0].kind == 1 ? tabs : tile) + a.off[0] + kq * se0 + x16 * sc0;
         const double *p1 = (a.f[1].kind == 1 ? tabs : tile) + a.off[1] + kq * se1 + x16 * sc1;
         const double *p2 = (a.f[2].kind == 1 ? tabs : tile) + a.off[2] + kq * se2 + x16 * sc2;
-#pragma unroll 2
-        for (int b = 0; b < SG_T / 4; ++b) {
-            const int e = 4 * b + kq;
-            const int je = rj[e];
-            const bool ok = je >= 0;
-            const double v = rv[e];
-            double av[NT], bv[NT], cv[NT];
+#ifdef TTSK_LAB
+        if (a.lab & 2) continue;
+#endif
+        // operands of k-block b: (val A)[e][c], B[e][c], C[e][c] for e = 4 b + kq, c = 16 t + x16; zero beyond the widths / the stretch
+        auto operands = [&](int b, bool ok, double v, double (&av)[NT], double (&bv)[NT], double (&cv)[NT]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c = 16 * t + x16;
-                av[t] = a.f[0].kind ? (ok && c < wA ? p0[4 * b * se0 + 16 * t * sc0] : 0.0) : (c == 0 ? 1.0 : 0.0);
-                bv[t] = a.f[1].kind ? (ok && c < wB ? p1[4 * b * se1 + 16 * t * sc1] : 0.0) : (c == 0 ? 1.0 : 0.0);
-                av[t] *= v;
-                cv[t] = 0.0;
+                const double la = p0[4 * b * se0 + 16 * t * sc0], lb = p1[4 * b * se1 + 16 * t * sc1], lc = p2[4 * b * se2 + 16 * t * sc2];
+                const double one = c == 0 ? 1.0 : 0.0;
+                av[t] = (a.f[0].kind ? (ok && c < wA ? la : 0.0) : one) * v;
+                bv[t] = a.f[1].kind ? (ok && c < wB ? lb : 0.0) : one;
+                cv[t] = (a.has_om && ok && c < a.f[2].w) ? lc : 0.0;
             }
-            if (a.has_om) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int c = 16 * t + x16;
-                    cv[t] = (ok && c < a.f[2].w) ? p2[4 * b * se2 + 16 * t * sc2] : 0.0;
-                }
-#pragma unroll
-                for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < NT; ++tb)
-                        accO[ta][tb] = a.c_left ? mfma16(cv[ta] * v, bv[tb], accO[ta][tb]) : mfma16(av[ta], cv[tb], accO[ta][tb]);
-            }
-            if (__ballot(ok && je != cur) == 0ull) {
-#pragma unroll
-                for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
-            } else {
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int okq = __shfl((int)ok, 16 * qq);
-                    const int jq = __shfl(je, 16 * qq);
-                    if (!okq) continue;
-                    if (jq != cur) {
-                        flush(cur, false);
-                        cur = jq;
-                    }
+        };
+        if (tile_one_slice) {
+            // every nonzero of the tile belongs to the running slice (all but one tile in ~10^3 at C4): no slice test per
+            // k-block, the validity bits from the ballot of stage (1), nothing but loads and matrix instructions in the loop
+            constexpr int SG_UNR = NT == 1 ? 4 : 1;
+            auto run = [&](auto with_om) {
+#pragma unroll SG_UNR
+                for (int b = 0; b < SG_T / 4; ++b) {
+                    const int e = 4 * b + kq;
+                    const bool ok = (vbits >> e) & 1u;
+                    double av[NT], bv[NT], cv[NT];
+                    operands(b, ok, rv[e], av, bv, cv);
 #pragma unroll
                     for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
-                        for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(kq == qq ? av[ta] : 0.0, bv[tb], accP[ta][tb]);
+                        for (int tb = 0; tb < NT; ++tb) {
+                            if constexpr (decltype(with_om)::value)
+                                accO[ta][tb] = mfma16(a.c_left ? cv[ta] * rv[e] : av[ta], a.c_left ? bv[tb] : cv[tb], accO[ta][tb]);
+                            accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
+                        }
+                }
+            };
+            if (a.has_om) run(std::true_type{});
+            else run(std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int b = 0; b < SG_T / 4; ++b) {
+                const int e = 4 * b + kq;
+                const int je = rj[e];
+                const bool ok = je >= 0;
+                const double v = rv[e];
+                double av[NT], bv[NT], cv[NT];
+                operands(b, ok, v, av, bv, cv);
+                if (a.has_om) {
+#pragma unroll
+                    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < NT; ++tb)
+                            accO[ta][tb] = a.c_left ? mfma16(cv[ta] * v, bv[tb], accO[ta][tb]) : mfma16(av[ta], cv[tb], accO[ta][tb]);
+                }
+                if (__ballot(ok && je != cur) == 0ull) {
+#pragma unroll
+                    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
+                } else {
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int okq = __shfl((int)ok, 16 * qq);
+                        const int jq = __shfl(je, 16 * qq);
+                        if (!okq) continue;
+                        if (jq != cur) {
+                            flush(cur, false);
+                            cur = jq;
+                        }
+#pragma unroll
+                        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                            for (int tb = 0; tb < NT; ++tb) accP[ta][tb] = mfma16(kq == qq ? av[ta] : 0.0, bv[tb], accP[ta][tb]);
+                    }
                 }
             }
         }
@@ -508,6 +548,9 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
         if (F.w > widest) widest = F.w;
     }
     const int NT = widest > 16 ? 2 : 1;
+#ifdef TTSK_LAB
+    { const char *e = getenv("TTSK_SG_LAB"); a.lab = e ? atoi(e) : 0; }
+#endif
     a.has_om = C != nullptr;
     a.c_left = c_left;
     a.tcols = cols > 0 ? cols : 1;
