@@ -270,7 +270,7 @@ int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const in
                             const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
                             const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream);
 /* one DRM factor of a pass: kind 0 = ones (width 1), 1 = table[flat][w] (every possible prefix sampled once:
- * ttsk_sparse_normal_table / ttsk_sparse_sign_table), 2 = normals sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c)
+ * ttsk_sparse_normal_table / ttsk_sparse_sign_table; allocated with one spare row: rows are fetched in 16-byte units), 2 = normals sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c)
  * + seed))), 3 = sparse-sign rows sampled in the pass (fast_lazy_gaussian.pyx:121-180; whole row <= 32 entries);
  * flat = src 0: prefix, 1: suffix, 2: prefix + j * mul, 3: suffix + j * mul (the prefix / suffix one mode longer) */
 typedef struct {

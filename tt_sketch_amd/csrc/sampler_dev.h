@@ -63,102 +63,125 @@ __device__ __forceinline__ double mant_unit(uint64_t bits)
     return __longlong_as_double((bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL) - 1.0;
 }
 
-// the central branch of ndtri_dev alone (exp(-2) < y0 <= 1 - exp(-2): 73 % of the samples), for callers that have made the
-// case distinction themselves: the same operations in the same order, hence the same bits
+// ---- Cephes ndtri (fast_lazy_gaussian.pyx:183-202 -> scipy.special.cython_special.ndtri), restated for the vector ALU.
+// The operations and their order are those of the C source, so the results are its bits wherever the host libm's log agrees with
+// the device's (the 8-ulp bar of DESIGN section 3 is for that).  What is written by hand, because the samplers are bound by
+// the vector ALU and each of these is instructions saved without touching a result bit:
+//   * a Horner step p * z + c is ONE v_fma_f64 with c read from a scalar register pair (the compiler's form is a v_mov_b32
+//     pair per constant -- a 64-bit literal does not exist -- plus v_fmac: 104 moves in 440 instructions of the tail);
+//   * a / b is the reciprocal-Newton-residual sequence the compiler emits, without its v_div_scale / v_div_fixup frame: those
+//     rescale operands near the ends of the exponent range and patch infinities, zeros and NaNs, none of which occur for the
+//     polynomial values and x in [2, 38.6] divided here (same bits otherwise: the frame multiplies by 1);
+//   * the far tail (x >= 8: y < exp(-32), one sample in 10^14) is a real branch, not both rational functions and a select.
+__device__ __forceinline__ double nd_fma_c(double a, double b, double c)          // a * b + c, c a constant in scalar registers
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+__device__ __forceinline__ double nd_div(double a, double b)                      // a / b, correctly rounded, operands in range (above)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+
+// the central branch alone (exp(-2) < y0 <= 1 - exp(-2): 73 % of the samples), for callers that have made the case distinction
 __device__ __forceinline__ double ndtri_central_dev(double y0)
 {
     const double s2pi = 2.50662827463100050242E0;
     const double y = y0 - 0.5;
     const double y2 = y * y;
     double p = -5.99633501014107895267E1;
-    p = p * y2 + 9.80010754185999661536E1;
-    p = p * y2 - 5.66762857469070293439E1;
-    p = p * y2 + 1.39312609387279679503E1;
-    p = p * y2 - 1.23916583867381258016E0;
+    p = nd_fma_c(p, y2, 9.80010754185999661536E1);
+    p = nd_fma_c(p, y2, -5.66762857469070293439E1);
+    p = nd_fma_c(p, y2, 1.39312609387279679503E1);
+    p = nd_fma_c(p, y2, -1.23916583867381258016E0);
     double q = y2 + 1.95448858338141759834E0;
-    q = q * y2 + 4.67627912898881538453E0;
-    q = q * y2 + 8.63602421390890590575E1;
-    q = q * y2 - 2.25462687854119370527E2;
-    q = q * y2 + 2.00260212380060660359E2;
-    q = q * y2 - 8.20372256168333339912E1;
-    q = q * y2 + 1.59056225126211695515E1;
-    q = q * y2 - 1.18331621121330003142E0;
-    const double x = y + y * (y2 * p / q);
+    q = nd_fma_c(q, y2, 4.67627912898881538453E0);
+    q = nd_fma_c(q, y2, 8.63602421390890590575E1);
+    q = nd_fma_c(q, y2, -2.25462687854119370527E2);
+    q = nd_fma_c(q, y2, 2.00260212380060660359E2);
+    q = nd_fma_c(q, y2, -8.20372256168333339912E1);
+    q = nd_fma_c(q, y2, 1.59056225126211695515E1);
+    q = nd_fma_c(q, y2, -1.18331621121330003142E0);
+    const double x = __builtin_fma(y, nd_div(y2 * p, q), y);
     return x * s2pi;
+}
+
+// z p(z) / q(z) for x = 1 / z >= 8: never on a hot path
+__device__ __attribute__((noinline)) double ndtri_far_tail_dev(double z)
+{
+    double p = 3.23774891776946035970E0;
+    p = p * z + 6.91522889068984211695E0;
+    p = p * z + 3.93881025292474443415E0;
+    p = p * z + 1.33303460815807542389E0;
+    p = p * z + 2.01485389549179081538E-1;
+    p = p * z + 1.23716634817820021358E-2;
+    p = p * z + 3.01581553508235416007E-4;
+    p = p * z + 2.65806974686737550832E-6;
+    p = p * z + 6.23974539184983293730E-9;
+    double q = z + 6.02427039364742014255E0;
+    q = q * z + 3.67983563856160859403E0;
+    q = q * z + 1.37702099489081330271E0;
+    q = q * z + 2.16236993594496635890E-1;
+    q = q * z + 1.34204006088543189037E-2;
+    q = q * z + 3.28014464682127739104E-4;
+    q = q * z + 2.89247864745380683936E-6;
+    q = q * z + 6.79019408009981274425E-9;
+    return z * p / q;
+}
+
+// the tails alone: 0 < y0 <= exp(-2) or y0 > 1 - exp(-2)
+__device__ __forceinline__ double ndtri_tail_dev(double y0)
+{
+    const double expm2 = 0.13533528323661269189;
+    int code = 1;
+    double y = y0;
+    if (y > 1.0 - expm2) { y = 1.0 - y; code = 0; }
+    double x = sqrt(-2.0 * log(y));
+    const double x0 = x - nd_div(log(x), x);
+    const double z = nd_div(1.0, x);
+    double x1;
+    if (x < 8.0) {
+        double p = 4.05544892305962419923E0;
+        p = nd_fma_c(p, z, 3.15251094599893866154E1);
+        p = nd_fma_c(p, z, 5.71628192246421288162E1);
+        p = nd_fma_c(p, z, 4.40805073893200834700E1);
+        p = nd_fma_c(p, z, 1.46849561928858024014E1);
+        p = nd_fma_c(p, z, 2.18663306850790267539E0);
+        p = nd_fma_c(p, z, -1.40256079171354495875E-1);
+        p = nd_fma_c(p, z, -3.50424626827848203418E-2);
+        p = nd_fma_c(p, z, -8.57456785154685413611E-4);
+        double q = z + 1.57799883256466749731E1;
+        q = nd_fma_c(q, z, 4.53907635128879210584E1);
+        q = nd_fma_c(q, z, 4.13172038254672030440E1);
+        q = nd_fma_c(q, z, 1.50425385692907503408E1);
+        q = nd_fma_c(q, z, 2.50464946208309415979E0);
+        q = nd_fma_c(q, z, -1.42182922854787788574E-1);
+        q = nd_fma_c(q, z, -3.80806407691578277194E-2);
+        q = nd_fma_c(q, z, -9.33259480895457427372E-4);
+        x1 = nd_div(z * p, q);
+    } else {
+        x1 = ndtri_far_tail_dev(z);
+    }
+    x = x0 - x1;
+    return code ? -x : x;
 }
 
 __device__ inline double ndtri_dev(double y0)
 {
-    const double s2pi = 2.50662827463100050242E0;
     const double expm2 = 0.13533528323661269189;
     if (y0 == 0.0) return -INFINITY;
     if (y0 == 1.0) return INFINITY;
-    int code = 1;
-    double y = y0;
-    if (y > 1.0 - expm2) { y = 1.0 - y; code = 0; }
-    if (y > expm2) {
-        y -= 0.5;
-        double y2 = y * y;
-        double p = -5.99633501014107895267E1;
-        p = p * y2 + 9.80010754185999661536E1;
-        p = p * y2 - 5.66762857469070293439E1;
-        p = p * y2 + 1.39312609387279679503E1;
-        p = p * y2 - 1.23916583867381258016E0;
-        double q = y2 + 1.95448858338141759834E0;
-        q = q * y2 + 4.67627912898881538453E0;
-        q = q * y2 + 8.63602421390890590575E1;
-        q = q * y2 - 2.25462687854119370527E2;
-        q = q * y2 + 2.00260212380060660359E2;
-        q = q * y2 - 8.20372256168333339912E1;
-        q = q * y2 + 1.59056225126211695515E1;
-        q = q * y2 - 1.18331621121330003142E0;
-        double x = y + y * (y2 * p / q);
-        return x * s2pi;
-    }
-    double x = sqrt(-2.0 * log(y));
-    double x0 = x - log(x) / x;
-    double z = 1.0 / x;
-    double p, q;
-    if (x < 8.0) {
-        p = 4.05544892305962419923E0;
-        p = p * z + 3.15251094599893866154E1;
-        p = p * z + 5.71628192246421288162E1;
-        p = p * z + 4.40805073893200834700E1;
-        p = p * z + 1.46849561928858024014E1;
-        p = p * z + 2.18663306850790267539E0;
-        p = p * z - 1.40256079171354495875E-1;
-        p = p * z - 3.50424626827848203418E-2;
-        p = p * z - 8.57456785154685413611E-4;
-        q = z + 1.57799883256466749731E1;
-        q = q * z + 4.53907635128879210584E1;
-        q = q * z + 4.13172038254672030440E1;
-        q = q * z + 1.50425385692907503408E1;
-        q = q * z + 2.50464946208309415979E0;
-        q = q * z - 1.42182922854787788574E-1;
-        q = q * z - 3.80806407691578277194E-2;
-        q = q * z - 9.33259480895457427372E-4;
-    } else {
-        p = 3.23774891776946035970E0;
-        p = p * z + 6.91522889068984211695E0;
-        p = p * z + 3.93881025292474443415E0;
-        p = p * z + 1.33303460815807542389E0;
-        p = p * z + 2.01485389549179081538E-1;
-        p = p * z + 1.23716634817820021358E-2;
-        p = p * z + 3.01581553508235416007E-4;
-        p = p * z + 2.65806974686737550832E-6;
-        p = p * z + 6.23974539184983293730E-9;
-        q = z + 6.02427039364742014255E0;
-        q = q * z + 3.67983563856160859403E0;
-        q = q * z + 1.37702099489081330271E0;
-        q = q * z + 2.16236993594496635890E-1;
-        q = q * z + 1.34204006088543189037E-2;
-        q = q * z + 3.28014464682127739104E-4;
-        q = q * z + 2.89247864745380683936E-6;
-        q = q * z + 6.79019408009981274425E-9;
-    }
-    double x1 = z * p / q;
-    x = x0 - x1;
-    return code ? -x : x;
+    if (y0 > expm2 && y0 <= 1.0 - expm2) return ndtri_central_dev(y0);
+    return ndtri_tail_dev(y0);
 }
 
 

@@ -35,6 +35,7 @@ struct SgF {
     uint64_t mul, seed;
     const double *table;
     int full, nnz;       // kind 3: length of the whole DRM row ([rank_min, rank_min + w) of it is used), its +-1 entries
+    int units, rcp;      // kind 1: a row of the staged block is ceil(w / 2) units of 16 bytes; floor(65536 / units) + 1
 };
 
 struct SgPass {
@@ -46,7 +47,7 @@ struct SgPass {
     SgF f[3];            // Psi = (val A) (x) B by slice; Omega = (val C) (x) B  (c_left)  or  (val A) (x) C
     int c_left, has_om;
     int off[3], tcols;   // sampled factor: column offset in the staged tile (of what the products read), the tile's row length;
-    int tab;             // table factor: offset of its block [w][SG_TP] behind the tile; doubles of all table blocks
+    int tab;             // table factor: offset of its block [SG_T][2 units] behind the tile; doubles of all table blocks
     int qcols;           // columns of the sampled factors: the tail queue holds at most SG_T * qcols slots
     double *psi;         // [wA][n][wB]
     double *part_psi;    // [wave][2][wA * wB]
@@ -58,7 +59,6 @@ struct SgPass {
 };
 
 constexpr int SG_T = 32;         // nonzeros per staged tile
-constexpr int SG_TP = SG_T + 1;  // pitch of a table block's columns (the products read 16 columns at one nonzero: distinct banks)
 
 // ndtri as a CALL in this kernel: inlined at its two sites it takes the pass kernel to ~230 VGPRs (two waves per SIMD,
 // or 49 spilled registers under a tighter cap); the call costs a few scalar instructions per ~100 of arithmetic.
@@ -72,7 +72,7 @@ __device__ __forceinline__ uint64_t sg_flat(const SgF &f, uint64_t fl, uint64_t 
 
 __host__ __device__ inline size_t sg_per_wave(int tcols, int tab, int qcols)
 {
-    return (size_t)SG_T * tcols + tab + 3 * SG_T + SG_T / 2 + ((size_t)SG_T * qcols + 3) / 4;
+    return (size_t)SG_T * tcols + tab + 4 * SG_T + SG_T / 2 + ((size_t)SG_T * qcols + 3) / 4;
 }
 
 // NT: 16-column matrix tiles per factor.  NT = 1 (every factor <= 16 columns: C4) is the round-3 kernel; NT = 2 takes
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     }
     __syncthreads();                                   // the only workgroup barrier: waves run free from here
     const int tcols = a.tcols;
-    // per-wave LDS: tile[SG_T][tcols] (the sampled factors) | table blocks [w][SG_TP] | fl[SG_T] | fr[SG_T] | val[SG_T] | j[SG_T] (int) |
+    // per-wave LDS: tile[SG_T][tcols] (the sampled factors) | table blocks [SG_T][2 units] | byte offsets of the table rows [3][SG_T] | val[SG_T] | j[SG_T] (int) |
     // queue (ushort, SG_T * qcols)
     const size_t per_wave = sg_per_wave(tcols, a.tab, a.qcols);
     double *tile = sg_lds + (size_t)wv * per_wave;
     double *tabs = tile + SG_T * tcols;
-    uint64_t *rfl = (uint64_t *)(tabs + a.tab), *rfr = rfl + SG_T;
-    double *rv = (double *)(rfr + SG_T);
+    uint64_t *ro = (uint64_t *)(tabs + a.tab);
+    double *rv = (double *)(ro + 3 * SG_T);
     int *rj = (int *)(rv + SG_T);
     unsigned short *q = (unsigned short *)(rj + SG_T);
 
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         const int my_j = nx_j;
         const bool valid = my_j >= 0;
         if (lane < SG_T) {
-            rfl[lane] = my_fl; rfr[lane] = my_fr;
+#pragma unroll
+            for (int f = 0; f < 3; ++f)                // where the nonzero's row of table factor f starts (a missing nonzero: row 0)
+                if (a.f[f].kind == 1) ro[f * SG_T + lane] = valid ? sg_flat(a.f[f], my_fl, my_fr, my_j) * (uint64_t)(8 * a.f[f].w) : 0;
             rv[lane] = nx_v;
             rj[lane] = my_j;
         }
@@ -181,10 +183,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         const bool tile_one_slice = __ballot(valid && my_j != cur) == 0ull;
         rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
         __builtin_amdgcn_wave_barrier();
-        // ---- (2a) the table factors: row flat[t] of the table to column-major blocks [c][SG_TP] by LDS-DMA (lane = (nonzero
-        // lane >> 1, dword lane & 1); one instruction per column moves 32 doubles), no registers held: the rows of ALL table
-        // factors travel while the sampled factors are evaluated, and are waited for once, in front of the products
-        // (the register gather of rounds 3-4 paid one round trip per table factor: 0.6 ms per pass at C4)
+        // ---- (2a) the table factors: row flat[t] of the table into a block [t][2 units] by LDS-DMA, 16 bytes per lane (unit
+        // i = 64 k + lane of the block in instruction k: nonzero i / units, unit i % units of its row), no registers held: the rows
+        // of ALL table factors travel while the sampled factors are evaluated, and are waited for once, in front of the
+        // products.  (The register gather of rounds 3-4 paid one round trip per table factor; dword DMAs, one per column,
+        // were bound by the address unit: 40 instructions per tile at C4 against 7 now.)  An odd row's last unit reads 8 bytes
+        // of the next row (the table has a spare row behind its last one); rows are 8-byte aligned only.
 #pragma unroll 1
         for (int f = 0; f < 3; ++f) {
             const SgF &F = a.f[f];
@@ -192,15 +196,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #ifdef TTSK_LAB
             if (a.lab & 1) continue;
 #endif
-            const int t = lane >> 1;
-            const int jt = rj[t];
-            const uint64_t flat = jt >= 0 ? sg_flat(F, rfl[t], rfr[t], jt) : 0;
-            const char *src = (const char *)(F.table + flat * (uint64_t)F.w) + 4 * (lane & 1);
             double *blk = tabs + a.off[f];
 #pragma unroll 1
-            for (int c = 0; c < F.w; ++c)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 8 * c),
-                                                 (__attribute__((address_space(3))) void *)(blk + c * SG_TP), 4, 0, 0);
+            for (int i0 = 0; i0 < SG_T * F.units; i0 += 64) {
+                const int i = i0 + lane;
+                const int t = (i * F.rcp) >> 16, cu = i - t * F.units;
+                if (t < SG_T) {
+                    const char *src = (const char *)F.table + ro[f * SG_T + t] + 16 * cu;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(blk + 2 * i0), 16, 0, 0);
+                }
+            }
         }
         // ---- (2b) the sampled factors into the tile
         int qn = 0;
@@ -269,12 +275,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the table blocks have landed
         __builtin_amdgcn_wave_barrier();
         // ---- (4) the products: k-block b = nonzeros 4 b .. 4 b + 3 of the tile
-        // element (nonzero e, column c) of factor i: a table block is [c][SG_TP], a sampled factor [e][tcols]
-        const int sc0 = a.f[0].kind == 1 ? SG_TP : 1, sc1 = a.f[1].kind == 1 ? SG_TP : 1, sc2 = a.f[2].kind == 1 ? SG_TP : 1;
-        const int se0 = a.f[0].kind == 1 ? 1 : tcols, se1 = a.f[1].kind == 1 ? 1 : tcols, se2 = a.f[2].kind == 1 ? 1 : tcols;
-        const double *p0 = (a.f[0].kind == 1 ? tabs : tile) + a.off[0] + kq * se0 + x16 * sc0;
-        const double *p1 = (a.f[1].kind == 1 ? tabs : tile) + a.off[1] + kq * se1 + x16 * sc1;
-        const double *p2 = (a.f[2].kind == 1 ? tabs : tile) + a.off[2] + kq * se2 + x16 * sc2;
+        // element (nonzero e, column c) of factor i: at [e][pitch of its table block, or of the tile][c]
+        const int se0 = a.f[0].kind == 1 ? 2 * a.f[0].units : tcols, se1 = a.f[1].kind == 1 ? 2 * a.f[1].units : tcols,
+                  se2 = a.f[2].kind == 1 ? 2 * a.f[2].units : tcols;
+        const double *p0 = (a.f[0].kind == 1 ? tabs : tile) + a.off[0] + kq * se0 + x16;
+        const double *p1 = (a.f[1].kind == 1 ? tabs : tile) + a.off[1] + kq * se1 + x16;
+        const double *p2 = (a.f[2].kind == 1 ? tabs : tile) + a.off[2] + kq * se2 + x16;
 #ifdef TTSK_LAB
         if (a.lab & 2) continue;
 #endif
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c = 16 * t + x16;
-                const double la = p0[4 * b * se0 + 16 * t * sc0], lb = p1[4 * b * se1 + 16 * t * sc1], lc = p2[4 * b * se2 + 16 * t * sc2];
+                const double la = p0[4 * b * se0 + 16 * t], lb = p1[4 * b * se1 + 16 * t], lc = p2[4 * b * se2 + 16 * t];
                 const double one = c == 0 ? 1.0 : 0.0;
                 av[t] = (a.f[0].kind ? (ok && c < wA ? la : 0.0) : one) * v;
                 bv[t] = a.f[1].kind ? (ok && c < wB ? lb : 0.0) : one;
@@ -542,8 +548,10 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
             cols += F.w;
             a.qcols += F.w;
         } else if (F.kind == 1) {                      // a block of its own behind the tile
+            F.units = (F.w + 1) / 2;
+            F.rcp = 65536 / F.units + 1;              // i / units == (i * rcp) >> 16 for i < 1024, units <= 16
             a.off[i] = a.tab;
-            a.tab += F.w * SG_TP;
+            a.tab += SG_T * 2 * F.units;
         }
         if (F.w > widest) widest = F.w;
     }

@@ -78,7 +78,8 @@ class _Side:
         if self.sign:
             key += (int(drm.true_rank[k]), int(drm.nnz[k]))
         if key not in self.cache:
-            out = DevArray.empty((self.prefixes(k), self.width(k)))
+            # (one spare row: the pass kernel fetches rows in 16-byte units, the last unit of an odd row reaches 8 bytes on)
+            out = DevArray.empty((self.prefixes(k) + 1, self.width(k)))
             if self.sign:
                 nat.call("ttsk_sparse_sign_table", _u64(self.shape[:k + 1]), k + 1, int(drm.true_rank[k]), int(drm.rank_min[k]),
                          int(drm.rank_max[k]), int(drm.nnz[k]), ctypes.c_uint64(self.seed(k)), ctypes.c_void_p(out.ptr), 0)
