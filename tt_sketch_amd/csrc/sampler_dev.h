@@ -92,6 +92,39 @@ __device__ __forceinline__ double nd_div(double a, double b)                    
     return __builtin_fma(rem, r, q);
 }
 
+// log(x) for a positive normal x, error < 1 ulp: the classical reduction x = 2^k m, m in [sqrt(2)/2, sqrt(2)), f = m - 1,
+// s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 minimax R of Sun's fdlibm (e_log.c), the
+// two-part ln 2.  The compiler's library log is a double-double evaluation of ~110 instructions; two logarithms per tail
+// sample were the largest single item of the samplers' instruction count.  s is formed by reciprocal + two Newton steps
+// (its error enters scaled by f^2 / 2).  The host reference evaluates glibc's log (correctly rounded in nearly all cases):
+// neither this nor the library log reproduces its last bit, which is what the 8-ulp bar on the normals covers.
+__device__ __forceinline__ double nd_log(double x)
+{
+    const uint64_t bx = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(bx >> 32);
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t up = (hx + 0x95f64u) & 0x100000u;                 // mantissa >= sqrt(2): take m / 2, k + 1
+    const double m = __longlong_as_double((long long)(((uint64_t)(hx | (up ^ 0x3ff00000u)) << 32) | (bx & 0xffffffffull)));
+    k += (int)(up >> 20);
+    const double f = m - 1.0, dk = (double)k;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double s = f * r, z = s * s, w = z * z;
+    double t1 = w * 1.531383769920937332e-01 + 2.222219843214978396e-01;       // Lg6, Lg4
+    t1 = nd_fma_c(t1, w, 3.999999999940941908e-01) * w;                       // Lg2
+    double t2 = w * 1.479819860511658591e-01 + 1.818357216161805012e-01;       // Lg7, Lg5
+    t2 = nd_fma_c(t2, w, 2.857142874366239149e-01);                           // Lg3
+    t2 = nd_fma_c(t2, w, 6.666666666666735130e-01) * z;                       // Lg1
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return dk * ln2_hi - ((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
 // the central branch alone (exp(-2) < y0 <= 1 - exp(-2): 73 % of the samples), for callers that have made the case distinction
 __device__ __forceinline__ double ndtri_central_dev(double y0)
 {
@@ -145,8 +178,8 @@ __device__ __forceinline__ double ndtri_tail_dev(double y0)
     int code = 1;
     double y = y0;
     if (y > 1.0 - expm2) { y = 1.0 - y; code = 0; }
-    double x = sqrt(-2.0 * log(y));
-    const double x0 = x - nd_div(log(x), x);
+    double x = sqrt(-2.0 * nd_log(y));
+    const double x0 = x - nd_div(nd_log(x), x);
     const double z = nd_div(1.0, x);
     double x1;
     if (x < 8.0) {
