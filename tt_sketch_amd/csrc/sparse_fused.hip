@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     int *rj = (int *)(rv + SG_T);
     unsigned short *q = (unsigned short *)(rj + SG_T);
 
+    // (finite values everywhere a product may read: the rows of nonzeros beyond the stretch are multiplied by val = 0)
+    for (int i = lane; i < SG_T * tcols + a.tab; i += 64) tile[i] = 0.0;
     const size_t w_id = (size_t)blockIdx.x * 4 + wv;
     const size_t beg = w_id * a.chunk;
     const int wA = a.f[0].w, wB = a.f[1].w;
@@ -179,7 +181,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             rv[lane] = nx_v;
             rj[lane] = my_j;
         }
-        const unsigned vbits = (unsigned)__ballot(valid);                           // bit e: nonzero e of the tile exists
         const bool tile_one_slice = __ballot(valid && my_j != cur) == 0ull;
         rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
         __builtin_amdgcn_wave_barrier();
@@ -284,29 +285,29 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #ifdef TTSK_LAB
         if (a.lab & 2) continue;
 #endif
-        // operands of k-block b: (val A)[e][c], B[e][c], C[e][c] for e = 4 b + kq, c = 16 t + x16; zero beyond the widths / the stretch
-        auto operands = [&](int b, bool ok, double v, double (&av)[NT], double (&bv)[NT], double (&cv)[NT]) {
+        // operands of k-block b: (val A)[e][c], B[e][c], C[e][c] for e = 4 b + kq, c = 16 t + x16.  No masks: a column beyond a
+        // factor's width only reaches result cells that are never stored, and a nonzero beyond the stretch has val = 0 and finite
+        // (stale or zero-initialised) factor rows
+        auto operands = [&](int b, double v, double (&av)[NT], double (&bv)[NT], double (&cv)[NT]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int c = 16 * t + x16;
                 const double la = p0[4 * b * se0 + 16 * t], lb = p1[4 * b * se1 + 16 * t], lc = p2[4 * b * se2 + 16 * t];
-                const double one = c == 0 ? 1.0 : 0.0;
-                av[t] = (a.f[0].kind ? (ok && c < wA ? la : 0.0) : one) * v;
-                bv[t] = a.f[1].kind ? (ok && c < wB ? lb : 0.0) : one;
-                cv[t] = (a.has_om && ok && c < a.f[2].w) ? lc : 0.0;
+                const double one = 16 * t + x16 == 0 ? 1.0 : 0.0;
+                av[t] = (a.f[0].kind ? la : one) * v;
+                bv[t] = a.f[1].kind ? lb : one;
+                cv[t] = lc;
             }
         };
         if (tile_one_slice) {
             // every nonzero of the tile belongs to the running slice (all but one tile in ~10^3 at C4): no slice test per
             // k-block, the validity bits from the ballot of stage (1), nothing but loads and matrix instructions in the loop
-            constexpr int SG_UNR = NT == 1 ? 4 : 1;
+            constexpr int SG_UNR = NT == 1 ? 8 : 2;
             auto run = [&](auto with_om) {
 #pragma unroll SG_UNR
                 for (int b = 0; b < SG_T / 4; ++b) {
                     const int e = 4 * b + kq;
-                    const bool ok = (vbits >> e) & 1u;
                     double av[NT], bv[NT], cv[NT];
-                    operands(b, ok, rv[e], av, bv, cv);
+                    operands(b, rv[e], av, bv, cv);
 #pragma unroll
                     for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
                 const bool ok = je >= 0;
                 const double v = rv[e];
                 double av[NT], bv[NT], cv[NT];
-                operands(b, ok, v, av, bv, cv);
+                operands(b, v, av, bv, cv);
                 if (a.has_om) {
 #pragma unroll
                     for (int ta = 0; ta < NT; ++ta)
