@@ -833,6 +833,21 @@ def bench_c4(args, job):
                      gsamples_per_s=per_pass / (c["avg_us"] * 1e-6) * 1e-9, peak_gsamples_per_s=VALU_GSAMPLES,
                      frac=(per_pass / (c["avg_us"] * 1e-6) * 1e-9 / VALU_GSAMPLES) if per_pass else work / (c["avg_us"] * 1e-6) / (HBM_TBS * 1e12),
                      traffic=load_traffic(c["kernel"]), plan=plan)
+    # just outside the round-3 cover (<= 16 columns per factor, SparseGaussianDRM only): the same tensor with wider and with
+    # sign DRMs, a few sketches each; "ms_per_column" = time / DRM columns made per nonzero, the in-cover row first
+    cover = []
+    G, S = tsa.SparseGaussianDRM, tsa.SparseSignDRM
+    for name, mk in [("gaussian l=10 r=15 (in cover)", lambda: (G(l, shape, False, seed=3), G(r, shape, True, seed=4))),
+                     ("gaussian l=17 r=17", lambda: (G(17, shape, False, seed=3), G(17, shape, True, seed=4))),
+                     ("gaussian l=24 r=24", lambda: (G(24, shape, False, seed=3), G(24, shape, True, seed=4))),
+                     ("sign l=10 r=15", lambda: (S(l, shape, False, seed=3), S(r, shape, True, seed=4))),
+                     ("sign l=24 r=24", lambda: (S(24, shape, False, seed=3), S(24, shape, True, seed=4)))]:
+        ld, rd = mk()
+        _, med = timed_calls(nat, lambda: tsa.general_sketch(T, ld, rd, tsa.SketchMethod.streaming), reps=3)
+        cols = sparse_fused.last_plan.get("sampled_columns_per_nonzero", 0)
+        cover.append(dict(drm=name, ms=med, columns_per_nonzero=cols, ms_per_column=med / max(cols, 1)))
+    for c in cover:
+        c["per_column_vs_in_cover"] = c["ms_per_column"] / cover[0]["ms_per_column"]
     cpu = None
     if not args.no_cpu and job.world == 1:
         # the reference's Psi is O(n_mu nnz) boolean masks (sparse_sketch.py:18,60): nnz = 2e5 takes seconds, 1e7 minutes
@@ -860,7 +875,7 @@ def bench_c4(args, job):
                               what="SURVEY 8d bytes 8*nnz*(d+1) = 480 MB / wall time of one sketch (the per-class entry prices the passes "
                                    "against the fp64 VALU, which binds: every DRM row of a deep mode is an ndtri evaluation)",
                               gaussian_samples_per_s=samples / t_step, classes=classes,
-                              measured_valu_gsamples=dict(split=float(probe[0]), divergent=float(probe[1])),
+                              measured_valu_gsamples=dict(split=float(probe[0]), divergent=float(probe[1])), cover=cover,
                               first_call_ms=dict(h2d_and_upload=t_h2d * 1e3, first_sketch_incl_mode_sorts=t_first * 1e3,
                                                  steady_state=t_step * 1e3)),
                 cpu_baseline=cpu)
