@@ -360,9 +360,10 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
  *   Z (ll, Q, T) = sum_b C[b, .] X[b, ., .]     the first left product (dense_sketch.py:13-14 at mu = 0)
  *   U (n0, r, T) = sum_q P[q, .] X[., q, .]     Psi_0 before its last core (dense_sketch.py:36-52 at mu = 0)
  * The same call one level down gives Z_1 and Psi_1 from Z_0 (rows (p', i_1), C = the left DRM's second core as a matrix): a
- * first extent beyond 64 runs as blocks of 64 rows, Z summed over the blocks.
- * TTSK_ERR_UNSUPPORTED outside the kernel's cover: n0 = 32 or a multiple of 64, T % 16 == 0, Q % 8 == 0, ll <= 20, r even
- * and <= 40, Q T < 2^27, X, P and Z 16-byte aligned (the caller then forms the two products separately). */
+ * first extent beyond 64 runs as blocks of 64 rows (of 32 for ll > 20 or r > 40), Z summed over the blocks.
+ * TTSK_ERR_UNSUPPORTED outside the kernel's cover: n0 a multiple of 32, T % 16 == 0, Q % 8 == 0, ll <= 32, r <= 64
+ * (an odd r through a padded copy of P), Q T < 2^27, X, P and Z 16-byte aligned (the caller then forms the two
+ * products separately). */
 int ttsk_dense_first_pass(const double *dev_x, int64_t n0, int64_t Q, int64_t T, const double *dev_c, int64_t ll,
                           const double *dev_p, int64_t r, double *dev_z, double *dev_u, int stream);
 

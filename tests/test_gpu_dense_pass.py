@@ -32,7 +32,12 @@ SHAPES = [(32, 8, 16, 20, 40), (64, 8, 16, 20, 40), (64, 24, 32, 20, 40), (32, 4
           (32, 40, 48, 7, 22), (64, 16, 64, 16, 32), (32, 72, 128, 17, 34), (64, 264, 64, 3, 2), (64, 8, 16, 1, 40),
           (32, 16, 256, 20, 38), (64, 16, 16, 20, 40), (32, 2056, 16, 9, 12),
           # first mode beyond 64: blocks of 64 with partial Z (what the second pair of a sketch runs on)
-          (128, 16, 16, 20, 40), (192, 40, 32, 7, 22), (1280, 64, 64, 20, 40), (640, 512, 16, 20, 40)]
+          (128, 16, 16, 20, 40), (192, 40, 32, 7, 22), (1280, 64, 64, 20, 40), (640, 512, 16, 20, 40),
+          # beyond ranks 20 / 40: 3 and 4 column tiles, 2 row tiles, odd right ranks (padded copy of P),
+          # first modes that are multiples of 32 only; every pairing of the accumulator shapes
+          (64, 24, 32, 21, 42), (32, 4096, 16, 21, 42), (64, 40, 48, 32, 64), (32, 72, 128, 25, 48), (64, 264, 64, 20, 41),
+          (32, 16, 16, 32, 40), (64, 16, 32, 24, 39), (96, 40, 32, 7, 22), (96, 24, 16, 30, 57), (160, 64, 64, 21, 64),
+          (64, 8, 16, 20, 49), (32, 8, 16, 1, 1), (64, 2056, 16, 29, 33)]
 
 
 @pytest.mark.parametrize("n0,Q,T,ll,r", SHAPES)
@@ -52,17 +57,16 @@ def test_first_pass_against_einsum(tsa, n0, Q, T, ll, r):
     assert _rel(U.get(), np.einsum("qp,bqt->bpt", P, X)) < 1e-13
 
 
-@pytest.mark.parametrize("bad", ["n0", "T", "Q", "ll", "r", "odd r", "partials"])
+@pytest.mark.parametrize("bad", ["n0", "T", "Q", "ll", "r", "partials"])
 def test_first_pass_declines_outside_its_cover(tsa, bad):
     from tt_sketch_amd import _native as nat
     from tt_sketch_amd.device import DevArray
     n0, Q, T, ll, r = 32, 16, 16, 20, 40
-    if bad == "n0": n0 = 96
+    if bad == "n0": n0 = 48
     if bad == "T": T = 24
     if bad == "Q": Q = 10
-    if bad == "ll": ll = 21
-    if bad == "r": r = 42
-    if bad == "odd r": r = 39
+    if bad == "ll": ll = 33
+    if bad == "r": r = 65
     if bad == "partials": n0, Q, T = 64 * 40, 8 * 1024, 128       # 40 blocks x 20 x 2^20 doubles of partial Z: 6.7 GB
     if bad == "partials":          # (declined before anything is touched: no 21 GB operand for this)
         X = C = P = Z = U = DevArray.empty((64,))
@@ -77,7 +81,10 @@ def test_first_pass_declines_outside_its_cover(tsa, bad):
 @pytest.mark.parametrize("shape,l,r,second", [((32, 16, 4, 6), 5, 8, False), ((64, 32, 8), 20, 40, False),
                                                ((32, 16, 5, 8, 3), 6, 10, False), ((32, 48, 6, 4), (4, 7, 9), (12, 10, 6), False),
                                                ((64, 16, 16, 16), 20, 40, True), ((32, 16, 16, 8), 4, 8, True),
-                                               ((32, 16, 16, 8, 2), (8, 5, 3, 2), (6, 10, 12, 14), True)])
+                                               ((32, 16, 16, 8, 2), (8, 5, 3, 2), (6, 10, 12, 14), True),
+                                               # ranks beyond 20 / 40, an odd right rank
+                                               ((64, 32, 8), 21, 42, False), ((64, 16, 16, 16), 32, 64, True),
+                                               ((32, 16, 16, 8), 24, 39, True), ((32, 16, 5, 8, 3), (30, 21, 9, 3), (57, 33, 20, 8), False)])
 def test_dense_sketch_with_the_first_pass_vs_oracle(tsa, monkeypatch, shape, l, r, second):
     """general_sketch of a DenseTensor with TensorTrainDRMs whose first two modes put it on the one-pass kernel (the right
     DRM's matrix meets the tensor's columns position by position, so its outermost core carries the size of mode 1): every

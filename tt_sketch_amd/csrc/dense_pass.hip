@@ -29,6 +29,12 @@
 // = 4.03e9 over 1024 SIMDs agrees); the HBM side is 8.59 + 2.68 GB = 2.1 ms at the 5.5 TB/s a mixed stream reaches.
 // Measured: 2.58 - 2.66 ms = 0.62 - 0.64 of the matrix peak, 4.2 - 4.4 TB/s; the same instruction stream
 // takes 2.05 ms without its loads and stores.
+//
+// Ranks beyond 20 / 40 (round 4): the kernel is a template over the shapes of its two accumulator sets -- U: TP tiles of 16
+// columns + SP strips of 4 (r <= 16 TP + 4 SP), Z: ZT tiles of 16 rows + ZS strips (ll <= 16 ZT + 4 ZS).  (2 + 2, 1 + 1) is the
+// C2 instantiation above; r <= 48 runs 3 + 0, r <= 64 4 + 0, ll <= 32 2 + 0, with NBW = 4 (blocks of 32 values of b: 128
+// accumulator registers at 4 + 0) -- a first mode of 64 is then two blocks, their partial Z summed as for longer modes.  An odd
+// r reads a copy of P padded to r + 1 columns (16-byte units need an even row).
 #include "common.h"
 #include <type_traits>
 
@@ -61,26 +67,30 @@ struct DensePass {
     const double *C;
     int ll;
     const double *P;
-    int r;
+    int r, pr;             // columns of P in use, its row length (even)
     double *Z;
-    double *slab;          // [workgroup][NB][10][64]: the accumulators as the lanes hold them
+    double *slab;          // [workgroup][NB][4 TP + SP][64]: the accumulators as the lanes hold them
     int nt, nqc;           // t ranges (T / 16), q chunks (a multiple of 8)
     int64_t zblock;        // first mode beyond 64: blocks of 64 values of b, blockIdx = block * nt * nqc + ...; block k's partial Z at Z + k * zblock
     int dbg;               // diagnostics (TTSK_DP_DBG): 1 = no tile loads after the first, 2 = no Z stores, 4 = no rotated start, 8 = loads and stores of a tile in one burst
 };
 
-constexpr int DP_PROW = 48;        // doubles per row of the P image (40 used; 48 = 96 dwords: rows kq, kq + 1 on disjoint banks)
-constexpr int DP_PBUF = 8 * DP_PROW;
+// doubles per row of the P image: the columns in use rounded up to 16 mod 32 (rows kq, kq + 1 on disjoint halves of the banks):
+// 48 for 2 tiles + 2 strips (40 used) and for 3 tiles, 80 for 4 tiles
+constexpr int dp_prow(int TP, int SP) { return (16 * TP + 4 * SP + 15) / 32 * 32 + 16; }
 
-template <int NBW>
+template <int NBW, int TP, int SP, int ZT, int ZS>
 __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 {
     constexpr int NB = 8 * NBW;
+    constexpr int DP_PROW = dp_prow(TP, SP), DP_PBUF = 8 * DP_PROW, DP_PU = DP_PROW / 2;
+    constexpr int CW = 16 * ZT + 4 * ZS;           // columns of C held
+    static_assert((8 * DP_PU) % 64 == 0 && 8 * DP_PU <= 512, "the rows of P are brought by whole waves");
     extern __shared__ double lds[];
     double *Xl = lds;                              // [2][NB][8][16]
     double *Pl = Xl + 2 * NB * 128;                // [2][8][DP_PROW]
-    double *Cf = Pl + 2 * DP_PBUF;                 // [NB][16]   columns 0..15 of C
-    double *Cs = Cf + NB * 16;                     // [NB][4]    columns 16..19
+    double *Cf = Pl + 2 * DP_PBUF;                 // [ZT][NB][16]   columns 16 zt .. of C
+    double *Cs = Cf + ZT * NB * 16;                // [ZS][NB][4]    columns 16 ZT + 4 zs ..
 
     const int tid = threadIdx.x, lane = tid & 63, x16 = lane & 15, kq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,20 +101,21 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     const int total = a.Q >> 3;
     const int it_beg = (int)((int64_t)qc * total / a.nqc), it_end = (int)((int64_t)(qc + 1) * total / a.nqc);
 
-    for (int e = tid; e < NB * 20; e += 512) {
-        const int b = e / 20, c = e - 20 * b;
+    for (int e = tid; e < NB * CW; e += 512) {
+        const int b = e / CW, c = e - CW * b;
         const double v = c < a.ll ? a.C[((int64_t)bb * NB + b) * a.ll + c] : 0.0;
-        if (c < 16) Cf[b * 16 + c] = v; else Cs[b * 4 + c - 16] = v;
+        if (c < 16 * ZT) Cf[((c >> 4) * NB + b) * 16 + (c & 15)] = v;
+        else Cs[(((c - 16 * ZT) >> 2) * NB + b) * 4 + (c & 3)] = v;
     }
 
     // tile `it` (8 values of q) -> image `buf`: wave w brings the chunks of its own NBW values of b, one 1 KB instruction each
-    // (one row of the tensor = one page per instruction), row q of b's chunk to row q ^ (b & 1); waves 0..2 the 8 rows of P (24
-    // 16-byte units per row, the last 4 of them padding: whatever they read is never used).  Addresses as a wave-uniform 64-bit
-    // base plus a 32-bit lane offset (the saddr form: one register per lane, not two per chunk).
+    // (one row of the tensor = one page per instruction), row q of b's chunk to row q ^ (b & 1); the first waves the 8 rows of P
+    // (DP_PU 16-byte units per row, the last of them padding: whatever they read is never used).  Addresses as a wave-uniform
+    // 64-bit base plus a 32-bit lane offset (the saddr form: one register per lane, not two per chunk).
     const int xrow = lane >> 3, xcol = 2 * (lane & 7);
     const uint32_t xoff0 = (uint32_t)((xrow * a.T + xcol) * 8), xoff1 = (uint32_t)(((xrow ^ 1) * a.T + xcol) * 8);
-    const int pU = 64 * w + lane, prow = (pU / 24) & 7, ppair = pU % 24;
-    const uint32_t poff = (uint32_t)((prow * a.r + (2 * ppair + 2 <= a.r ? 2 * ppair : 0)) * 8);
+    const int pU = 64 * w + lane, prow = (pU / DP_PU) & 7, ppair = pU % DP_PU;
+    const uint32_t poff = (uint32_t)((prow * a.pr + (2 * ppair + 2 <= a.pr ? 2 * ppair : 0)) * 8);
     const char *xbase = (const char *)a.X + (((int64_t)bb * NB + w * NBW) * a.sb + t0) * 8;
     // (one chunk at a time: `issue_x(tile offset, image, u)` is spread over the steps of a tile -- eight load instructions in a
     // row from each of eight waves stall every wave's instruction stream, and with it the matrix pipes, behind the address unit:
@@ -116,8 +127,8 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
                                          (__attribute__((address_space(3))) void *)(Xl + (buf * NB + w * NBW + u) * 128), 16, 0, 2);
     };
     auto issue_p = [&](int it, int buf) {
-        if (w < 3) {
-            const char *src = (const char *)a.P + uniform_i64((int64_t)it * 8 * a.r * 8) + poff;
+        if (w < 8 * DP_PU / 64) {
+            const char *src = (const char *)a.P + uniform_i64((int64_t)it * 8 * a.pr * 8) + poff;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(Pl + buf * DP_PBUF + w * 128), 16, 0, 0);
         }
@@ -129,30 +140,39 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         issue_p(it, buf);
     };
 
-    v4d acc[NBW][2];
-    double accs[NBW][2];
+    v4d acc[NBW][TP];
+    double accs[NBW][SP > 0 ? SP : 1];
 #pragma unroll
-    for (int bi = 0; bi < NBW; ++bi)
+    for (int bi = 0; bi < NBW; ++bi) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            accs[bi][p] = 0.0;
+        for (int p = 0; p < TP; ++p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[bi][p][j] = 0.0;
-        }
+#pragma unroll
+        for (int p = 0; p < (SP > 0 ? SP : 1); ++p) accs[bi][p] = 0.0;
+    }
 
     // Z: wave w chains row q0 + w of the tile over all b; the row is stored while the next tile is computed on
-    v4d zp;
-    double zps = 0.0;
+    v4d zp[ZT];
+    double zps[ZS > 0 ? ZS : 1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zp[j] = 0.0;
+    for (int zt = 0; zt < ZT; ++zt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zp[zt][j] = 0.0;
+#pragma unroll
+    for (int zs = 0; zs < (ZS > 0 ? ZS : 1); ++zs) zps[zs] = 0.0;
     const int64_t zs_row = (int64_t)a.Q * a.T;
     const uint32_t zoff = (uint32_t)((kq * zs_row + x16) * 8);          // 3 Q T doubles at most: the host checks the range
     auto store_z = [&](int it) {
         const int64_t at = uniform_i64(((int64_t)bb * a.zblock + ((int64_t)it * 8 + w) * a.T + t0) * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (kq + 4 * j < a.ll) *(double *)((char *)a.Z + uniform_i64(at + 4 * j * zs_row * 8) + zoff) = zp[j];
-        if (16 + kq < a.ll) *(double *)((char *)a.Z + uniform_i64(at + 16 * zs_row * 8) + zoff) = zps;
+        for (int zt = 0; zt < ZT; ++zt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (16 * zt + kq + 4 * j < a.ll) *(double *)((char *)a.Z + uniform_i64(at + (16 * zt + 4 * j) * zs_row * 8) + zoff) = zp[zt][j];
+#pragma unroll
+        for (int zs = 0; zs < ZS; ++zs)
+            if (16 * ZT + 4 * zs + kq < a.ll) *(double *)((char *)a.Z + uniform_i64(at + (16 * ZT + 4 * zs) * zs_row * 8) + zoff) = zps[zs];
     };
 
     // The range is walked from a start that differs from workgroup to workgroup (the same for the nt workgroups that share
@@ -174,46 +194,79 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         // first matrix instruction of step s: the compiler puts lgkmcnt(0) in front of a step's first use, so the reads must
         // be neither younger than that wait nor right behind it; the scheduling barrier per step keeps that order -- left
         // alone, the compiler hoists every read of the tile to the front and spills the accumulators.
-        v4d z;
-        double zs = 0.0;
+        v4d z[ZT];
+        double zs[ZS > 0 ? ZS : 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) z[j] = 0.0;
+        for (int zt = 0; zt < ZT; ++zt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[zt][j] = 0.0;
+#pragma unroll
+        for (int q = 0; q < (ZS > 0 ? ZS : 1); ++q) zs[q] = 0.0;
         const int next_it = rel + 1 < len ? tile_of(rel + 1) : 0;
         const int64_t next_tile = uniform_i64((int64_t)next_it * 8 * a.T * 8);
         const double *xu = xb + w * NBW * 128 + x16;
         const double *xz = xb + kq * 128 + (w ^ (kq & 1)) * 16 + x16;
         const double *cf = Cf + kq * 16 + x16, *cs = Cs + kq * 4 + (x16 & 3);
-        const double *pr = pb + kq * DP_PROW + x16, *prs = pb + kq * DP_PROW + 32 + (x16 & 3);
-        double pf0 = pr[0], pf1 = pr[16], ps0 = prs[0], ps1 = prs[4];
-        double xf = xu[kq * 16], xzf = xz[0], cff = cf[0], csf = cs[0];
+        const double *pr = pb + kq * DP_PROW + x16, *prs = pb + kq * DP_PROW + 16 * TP + (x16 & 3);
+        double pf[TP], ps[SP > 0 ? SP : 1], cff[ZT], csf[ZS > 0 ? ZS : 1];
+#pragma unroll
+        for (int p = 0; p < TP; ++p) pf[p] = pr[16 * p];
+#pragma unroll
+        for (int p = 0; p < SP; ++p) ps[p] = prs[4 * p];
+#pragma unroll
+        for (int zt = 0; zt < ZT; ++zt) cff[zt] = cf[zt * NB * 16];
+#pragma unroll
+        for (int q = 0; q < ZS; ++q) csf[q] = cs[q * NB * 4];
+        double xf = xu[kq * 16], xzf = xz[0];
 #pragma unroll
         for (int s = 0; s < 2 * NBW; ++s) {
             const int bi = s % NBW;
-            double xf_n = 0.0, xz_n = 0.0, cf_n = 0.0, cs_n = 0.0, pf0_n = pf0, pf1_n = pf1, ps0_n = ps0, ps1_n = ps1;
+            double xf_n = 0.0, xz_n = 0.0, pf_n[TP], ps_n[SP > 0 ? SP : 1], cf_n[ZT], cs_n[ZS > 0 ? ZS : 1];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) pf_n[p] = pf[p];
+#pragma unroll
+            for (int p = 0; p < SP; ++p) ps_n[p] = ps[p];
+#pragma unroll
+            for (int zt = 0; zt < ZT; ++zt) cf_n[zt] = 0.0;
+#pragma unroll
+            for (int q = 0; q < ZS; ++q) cs_n[q] = 0.0;
             if (s + 1 < 2 * NBW) {
                 const int jn = (s + 1) / NBW, bn = (s + 1) % NBW;
                 xf_n = xu[bn * 128 + ((4 * jn + kq) ^ (bn & 1)) * 16];
                 xz_n = xz[(s + 1) * 512];
-                cf_n = cf[(s + 1) * 64];
-                cs_n = cs[(s + 1) * 16];
+#pragma unroll
+                for (int zt = 0; zt < ZT; ++zt) cf_n[zt] = cf[zt * NB * 16 + (s + 1) * 64];
+#pragma unroll
+                for (int q = 0; q < ZS; ++q) cs_n[q] = cs[q * NB * 4 + (s + 1) * 16];
                 if (bn == 0) {
-                    pf0_n = pr[4 * jn * DP_PROW];
-                    pf1_n = pr[4 * jn * DP_PROW + 16];
-                    ps0_n = prs[4 * jn * DP_PROW];
-                    ps1_n = prs[4 * jn * DP_PROW + 4];
+#pragma unroll
+                    for (int p = 0; p < TP; ++p) pf_n[p] = pr[4 * jn * DP_PROW + 16 * p];
+#pragma unroll
+                    for (int p = 0; p < SP; ++p) ps_n[p] = prs[4 * jn * DP_PROW + 4 * p];
                 }
             }
-            acc[bi][0] = mfma16(xf, pf0, acc[bi][0]);
-            z = mfma16(cff, xzf, z);
-            acc[bi][1] = mfma16(xf, pf1, acc[bi][1]);
-            accs[bi][0] = mfma4s(xf, ps0, accs[bi][0]);
-            accs[bi][1] = mfma4s(xf, ps1, accs[bi][1]);
-            zs = mfma4s(csf, xzf, zs);
-            xf = xf_n; xzf = xz_n; cff = cf_n; csf = cs_n;
-            pf0 = pf0_n; pf1 = pf1_n; ps0 = ps0_n; ps1 = ps1_n;
+            acc[bi][0] = mfma16(xf, pf[0], acc[bi][0]);
+            z[0] = mfma16(cff[0], xzf, z[0]);
+#pragma unroll
+            for (int p = 1; p < TP; ++p) acc[bi][p] = mfma16(xf, pf[p], acc[bi][p]);
+#pragma unroll
+            for (int zt = 1; zt < ZT; ++zt) z[zt] = mfma16(cff[zt], xzf, z[zt]);
+#pragma unroll
+            for (int p = 0; p < SP; ++p) accs[bi][p] = mfma4s(xf, ps[p], accs[bi][p]);
+#pragma unroll
+            for (int q = 0; q < ZS; ++q) zs[q] = mfma4s(csf[q], xzf, zs[q]);
+            xf = xf_n; xzf = xz_n;
+#pragma unroll
+            for (int p = 0; p < TP; ++p) pf[p] = pf_n[p];
+#pragma unroll
+            for (int p = 0; p < SP; ++p) ps[p] = ps_n[p];
+#pragma unroll
+            for (int zt = 0; zt < ZT; ++zt) cff[zt] = cf_n[zt];
+#pragma unroll
+            for (int q = 0; q < ZS; ++q) csf[q] = cs_n[q];
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + ZT + ZS + TP + SP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TP + SP + ZT + ZS - 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             // behind the first step, so that the matrix pipes start right after the barrier, and ONE instruction per step: the
             // next tile's loads (its image was last read before that barrier) at steps 1 .. NBW, the rows of P, then the
@@ -232,46 +285,48 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) zp[j] = z[j];
-        zps = zs;
+        for (int zt = 0; zt < ZT; ++zt) zp[zt] = z[zt];
+#pragma unroll
+        for (int q = 0; q < ZS; ++q) zps[q] = zs[q];
         // the next tile has landed (and the stores are done); no fence: LDS traffic of this wave complete, then the barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (len > 0 && !(DP_DBG(2))) store_z(tile_of(len - 1));
 
-    // the accumulators as they are: [b][slot][lane], slot = 4 * tile + register, 8 + strip
-    double *out = a.slab + ((int64_t)id * NB + w * NBW) * 640 + lane;
+    // the accumulators as they are: [b][slot][lane], slot = 4 * tile + register, 4 TP + strip
+    constexpr int SL = 4 * TP + SP;
+    double *out = a.slab + ((int64_t)id * NB + w * NBW) * (SL * 64) + lane;
 #pragma unroll
     for (int bi = 0; bi < NBW; ++bi) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < TP; ++p)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[(bi * 10 + 4 * p + j) * 64] = acc[bi][p][j];
-        out[(bi * 10 + 8) * 64] = accs[bi][0];
-        out[(bi * 10 + 9) * 64] = accs[bi][1];
+            for (int j = 0; j < 4; ++j) out[(bi * SL + 4 * p + j) * 64] = acc[bi][p][j];
+#pragma unroll
+        for (int p = 0; p < SP; ++p) out[(bi * SL + 4 * TP + p) * 64] = accs[bi][p];
     }
 }
 
 // U[b][p][t] = sum over the q chunks; one thread per accumulator element of a t range
-__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int nt, int nqc, int nbb, int T, int r, double *U)
+__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int TP, int SP, int nt, int nqc, int nbb, int T, int r, double *U)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int per = NB * 640;
+    const int sl64 = (4 * TP + SP) * 64, per = NB * sl64;
     if (e >= (int64_t)per * nt * nbb) return;
     const int bt = (int)(e / per), f = (int)(e - (int64_t)bt * per);
     const int bb = bt / nt, tr = bt - bb * nt;
-    const int b = f / 640, slot = (f - 640 * b) >> 6, l = f & 63;
+    const int b = f / sl64, slot = (f - sl64 * b) >> 6, l = f & 63;
     double s = 0.0;
     for (int qc = 0; qc < nqc; ++qc) {
         const int64_t id = (int64_t)bb * nt * nqc + (qc & 7) + 8 * (tr + nt * (qc >> 3));
         s += slab[id * per + f];
     }
     int p, t;
-    if (slot < 8) {                       // 16x16x4: register j of lane l is row (l >> 4) + 4 j, column l & 15
+    if (slot < 4 * TP) {                  // 16x16x4: register j of lane l is row (l >> 4) + 4 j, column l & 15
         p = 16 * (slot >> 2) + (l & 15);
         t = (l >> 4) + 4 * (slot & 3);
     } else {                              // 4x4x4: lane (i = l >> 4, beta = (l >> 2) & 3, c = l & 3) is row 4 beta + i, column c
-        p = 32 + 4 * (slot - 8) + (l & 3);
+        p = 16 * TP + 4 * (slot - 4 * TP) + (l & 3);
         t = 4 * ((l >> 2) & 3) + (l >> 4);
     }
     if (p < r) U[(((int64_t)bb * NB + b) * r + p) * T + 16 * tr + t] = s;
@@ -291,6 +346,29 @@ __global__ __launch_bounds__(256) void dense_pass_zsum(const double2 *part, int 
     Z[e] = s;
 }
 
+// P with one zero column appended (an odd r: the 16-byte units of the P loader need an even row)
+__global__ __launch_bounds__(256) void dense_pass_pad_p(const double *P, int64_t Q, int r, double *out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Q * (r + 1)) return;
+    const int64_t q = e / (r + 1);
+    const int c = (int)(e - q * (r + 1));
+    out[e] = c < r ? P[q * r + c] : 0.0;
+}
+
+template <int NBW, int TP, int SP, int ZT, int ZS>
+int dense_pass_launch(const DensePass &a, int64_t grid, hipStream_t st)
+{
+    constexpr int NB = 8 * NBW;
+    const size_t lds = (size_t)(2 * NB * 128 + 2 * 8 * dp_prow(TP, SP) + NB * (16 * ZT + 4 * ZS)) * 8;
+    static PerInit attr;
+    if (attr.first() && hipFuncSetAttribute((const void *)dense_pass_kernel<NBW, TP, SP, ZT, ZS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            156 * 1024) != hipSuccess)
+        return TTSK_ERR_HIP;
+    hipLaunchKernelGGL((dense_pass_kernel<NBW, TP, SP, ZT, ZS>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? TTSK_OK : TTSK_ERR_HIP;
+}
+
 }  // namespace
 
 }  // namespace ttsk
@@ -302,15 +380,19 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     TTSK_ARG(X && C && P && Z && U, "ttsk_dense_first_pass: NULL operand");
     TTSK_ARG(n0 > 0 && Q > 0 && T > 0 && ll > 0 && r > 0, "ttsk_dense_first_pass: empty extent");
     static const int on = [] { const char *e = getenv("TTSK_DENSE_ONE_PASS"); return e ? atoi(e) : 1; }();
-    if (!on || (n0 != 32 && (n0 & 63)) || n0 > 64 * 64 || (T & 15) || (Q & 7) || ll > 20 || r > 40 || (r & 1) || Q * T >= (1ll << 27) ||
+    if (!on || (n0 & 31) || n0 > 64 * 64 || (T & 15) || (Q & 7) || ll > 32 || r > 64 || Q * T >= (1ll << 27) ||
         (((uintptr_t)X | (uintptr_t)P | (uintptr_t)Z) & 15)) {
-        set_error("ttsk_dense_first_pass: shape outside the kernel's cover (first mode 32 or a multiple of 64, last mode a multiple "
-                  "of 16, middle extent a multiple of 8, left rank <= 20, even right rank <= 40)");
+        set_error("ttsk_dense_first_pass: shape outside the kernel's cover (first mode a multiple of 32, last mode a multiple "
+                  "of 16, middle extent a multiple of 8, left rank <= 32, right rank <= 64)");
         return TTSK_ERR_UNSUPPORTED;
     }
     TTSK_STREAM(st, stream);
     const int nt = (int)(T / 16);
-    const int NB = n0 == 32 ? 32 : 64, nbb = (int)(n0 / NB);
+    // accumulator shapes: U as TP tiles + SP strips of columns, Z as ZT tiles + ZS strips of rows; blocks of 64 values of b where
+    // the registers allow it (the C2 shape), of 32 otherwise
+    const int ushape = r <= 40 ? 0 : r <= 48 ? 1 : 2, zshape = ll <= 20 ? 0 : 1;
+    const int TP = ushape == 0 ? 2 : ushape == 1 ? 3 : 4, SP = ushape == 0 ? 2 : 0;
+    const int NB = (ushape == 0 && zshape == 0 && !(n0 & 63)) ? 64 : 32, nbb = (int)(n0 / NB);
     // q ranges: about 256 workgroups for one block of b, about 1024 over all blocks otherwise (several rounds over the CUs even
     // out the ranges); a multiple of 8, and not more than there are tiles
     int64_t nqc = 8 * std::max<int64_t>(1, (nbb == 1 ? 32 : (128 + nbb * nt / 2) / (nbb * nt)) / (nbb == 1 ? nt : 1));
@@ -318,14 +400,24 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     if (nqc_env > 0 && nbb > 1) nqc = 8 * cdiv(nqc_env, 8);
     nqc = std::min<int64_t>(nqc, 8 * cdiv(Q / 8, 8));          // at least one tile for most chunks
     const int64_t grid = (int64_t)nbb * nt * nqc;
+    const int64_t sl64 = (4 * TP + SP) * 64;
     // partial results beyond 4 GB (many blocks of a large operand): not this kernel's case -- the caller forms the products separately
-    if ((nbb > 1 && (int64_t)nbb * ll * Q * T * 8 > (4ll << 30)) || grid * NB * 640 * 8 > (4ll << 30)) {
+    if ((nbb > 1 && (int64_t)nbb * ll * Q * T * 8 > (4ll << 30)) || grid * NB * sl64 * 8 > (4ll << 30)) {
         set_error("ttsk_dense_first_pass: %d blocks of rows would need more than 4 GB of partial results", nbb);
         return TTSK_ERR_UNSUPPORTED;
     }
-    double *slab = (double *)scratch(stream, SCRATCH_MISC, (size_t)grid * NB * 640 * 8);
-    if (!slab) return TTSK_ERR_HIP;
-    // blocks of b: each block's Z is a partial sum over its 64 values of b
+    const int64_t pr = r + (r & 1);
+    const size_t pad_bytes = (r & 1) ? (size_t)Q * pr * 8 + 64 : 0;
+    char *ws = (char *)scratch(stream, SCRATCH_MISC, (size_t)grid * NB * sl64 * 8 + pad_bytes);
+    if (!ws) return TTSK_ERR_HIP;
+    double *slab = (double *)ws;
+    if (r & 1) {
+        double *pp = (double *)(ws + (size_t)grid * NB * sl64 * 8);
+        hipLaunchKernelGGL(dense_pass_pad_p, dim3((unsigned)cdiv(Q * pr, 256)), dim3(256), 0, st, P, Q, (int)r, pp);
+        TTSK_LAUNCH_CHECK();
+        P = pp;
+    }
+    // blocks of b: each block's Z is a partial sum over its values of b
     const int64_t zblock = ll * Q * T;
     double *zout = Z;
     if (nbb > 1) {
@@ -337,21 +429,16 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
 #else
     constexpr int dbg = 0;
 #endif
-    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, zout, slab, nt, (int)nqc, zblock, dbg};
-    const size_t lds = (size_t)(2 * NB * 128 + 2 * DP_PBUF + NB * 20) * 8;
-    static PerInit attr;
-    if (attr.first()) {
-        TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        TTSK_HIP(hipFuncSetAttribute((const void *)dense_pass_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    }
+    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, (int)pr, zout, slab, nt, (int)nqc, zblock, dbg};
     if (prof_on()) prof_open_named(st, PROF_SOLVE, 0.0, "dense_pass");
-    if (NB == 64)
-        hipLaunchKernelGGL(dense_pass_kernel<8>, dim3((unsigned)grid), dim3(512), lds, st, a);
-    else
-        hipLaunchKernelGGL(dense_pass_kernel<4>, dim3((unsigned)grid), dim3(512), lds, st, a);
-    TTSK_LAUNCH_CHECK();
-    const int64_t elems = (int64_t)NB * 640 * nt * nbb;
-    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, nt, (int)nqc, nbb, (int)T, (int)r, U);
+    int rc;
+    if (NB == 64) rc = dense_pass_launch<8, 2, 2, 1, 1>(a, grid, st);
+    else if (ushape == 0) rc = zshape == 0 ? dense_pass_launch<4, 2, 2, 1, 1>(a, grid, st) : dense_pass_launch<4, 2, 2, 2, 0>(a, grid, st);
+    else if (ushape == 1) rc = zshape == 0 ? dense_pass_launch<4, 3, 0, 1, 1>(a, grid, st) : dense_pass_launch<4, 3, 0, 2, 0>(a, grid, st);
+    else rc = zshape == 0 ? dense_pass_launch<4, 4, 0, 1, 1>(a, grid, st) : dense_pass_launch<4, 4, 0, 2, 0>(a, grid, st);
+    if (rc != TTSK_OK) { set_error("ttsk_dense_first_pass: launch failed"); return rc; }
+    const int64_t elems = (int64_t)NB * sl64 * nt * nbb;
+    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, TP, SP, nt, (int)nqc, nbb, (int)T, (int)r, U);
     TTSK_LAUNCH_CHECK();
     if (nbb > 1) {
         const int64_t pairs = zblock / 2;               // Q T is a multiple of 128

@@ -207,7 +207,7 @@ def _first_pass(A, B, X, mu: int = 0) -> bool:
         return False
     Q = cols // T
     ll, rho = int(A.core.shape[2]), int(B.core.shape[0])
-    if (rows != 32 and rows % 64) or T % 16 or Q % 8 or ll > 20 or rho > 40 or rho % 2 or Q * T >= 1 << 27:
+    if rows % 32 or T % 16 or Q % 8 or ll > 32 or rho > 64 or Q * T >= 1 << 27:
         return False
     P = B.prev._rows().contiguous()
     if tuple(P.shape) != (Q, rho):
