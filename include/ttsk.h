@@ -353,6 +353,15 @@ int ttsk_deferred_status(int stream, int *host_flag);
 int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
                         const double *const *X, const double *const *DL, const double *const *DR,
                         double *const *cores_out, double *const *omega_out, int stream);
+/* the same for `count` tensor trains of ONE signature (n, s) against ONE pair of DRMs -- the streaming setting of
+ * sketch.py:292-301, and the many same-shaped re-orthogonalisations of tt_gmres.py:293-299 -- as concurrent chains: tensor b
+ * on the library streams (stream + 2 (b mod 4), + 1), forked from and joined back into `stream`.
+ *   X, cores_out     count * d pointers, tensor-major;   omega_out   count * (d - 1) pointers (orthogonal)
+ *   dev_status       count ints in device memory: 1 = a fast factorisation of that tensor was rejected (repeat it on the
+ *                    robust path: ttsk_pinv / ttsk_qr_thin); read after ttsk_sync(stream) */
+int ttsk_tt_orth_sketch_batch(int count, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
+                              const double *const *X, const double *const *DL, const double *const *DR,
+                              double *const *cores_out, double *const *omega_out, int *dev_status, int stream);
 
 /* The two products of a dense-tensor sketch with tensor-train DRMs that read the tensor, from ONE read of it (reference
  * dense_sketch.py:7-52, sketch_omega_dense / sketch_psi_dense, with the DRM matrices of tensor_train_drm.py:109-122):

@@ -279,3 +279,88 @@ def test_assembly_matches_lstsq_for_ill_conditioned_omega(tsa, monkeypatch, dire
     e_pairs = tt_rel_diff(pairs, want)
     print("assembly vs lstsq:", e_one, e_pairs)
     assert e_one < 1e-11 and e_pairs < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# orthogonal_sketch_batch / hmt_sketch_batch (ttsk_tt_orth_sketch_batch): same-signature TTs as concurrent chains
+@pytest.mark.parametrize("shape,s_in,l,r,count", [
+    ((30, 28, 26, 24, 22), 12, 8, 16, 9),        # more tensors than stream pairs: a second tensor queues behind the first on a pair
+    ((64, 50, 50, 64), 33, 17, 40, 4),
+    ((200, 200, 200), 60, 50, 64, 3),
+])
+def test_orthogonal_sketch_batch_every_tensor_vs_oracle(tsa, shape, s_in, l, r, count):
+    """every tensor of the batch entry by entry against the oracle (sketch_dispatch.py:160-193), and
+    the batch equals the single calls bit for bit (the same kernels in the same order on another stream)."""
+    d = len(shape)
+    rng = np.random.default_rng(sum(shape) + count)
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left, right = _dev_drms(tsa, shape, (l,) * (d - 1), (r,) * (d - 1), ld, rd)
+    all_cores = [orc.random_tt(shape, s_in, rng) for _ in range(count)]
+    tts = [tsa.TensorTrain(c) for c in all_cores]
+    from tt_sketch_amd import tt_fused
+    assert tt_fused.try_orth_sketch_batch(tts, left, right, tsa.SketchMethod.orthogonal) is not None
+    got = tsa.orthogonal_sketch_batch(tts, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+    assert len(got) == count
+    for cores, tt in zip(all_cores, got):
+        want, _ = orc.general_sketch("tt", cores, ld, rd, "orthogonal")
+        _close([np.asarray(c) for c in tt.cores], want)
+    for k in (0, count - 1):
+        one = tsa.orthogonal_sketch(tts[k], (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+        for a, b in zip(one.cores, got[k].cores):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_hmt_sketch_batch_every_tensor_vs_oracle(tsa):
+    shape, s_in, r, count = (100, 100, 100, 100), 40, 32, 6
+    d = len(shape)
+    rng = np.random.default_rng(8)
+    rd = orc.random_tt_drm(shape, r, True, rng)
+    _, right = _dev_drms(tsa, shape, None, (r,) * (d - 1), None, rd)
+    all_cores = [orc.random_tt(shape, s_in, rng) for _ in range(count)]
+    got, drm = tsa.hmt_sketch_batch([tsa.TensorTrain(c) for c in all_cores], (r,) * (d - 1), drm=right, return_drm=True)
+    assert drm is right and len(got) == count
+    for cores, tt in zip(all_cores, got):
+        want, _ = orc.general_sketch("tt", cores, None, rd, "hmt")
+        _close([np.asarray(c) for c in tt.cores], want)
+
+
+def test_orthogonal_sketch_batch_verdict_per_tensor_and_fallbacks(tsa, monkeypatch):
+    """A rank-deficient tensor inside a batch (TT-rank 5 < l: its Omega have rank 5, the Cholesky attempts are rejected)
+    is repeated alone on the robust path -- its neighbours are not; a list that is not of one signature, and a dense
+    tensor, go through orthogonal_sketch one by one; the argument policy is orthogonal_sketch's."""
+    from tt_sketch_amd import sketch_dispatch
+    shape, l, r = (20, 22, 24, 26), 8, 14
+    d = len(shape)
+    rng = np.random.default_rng(11)
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left, right = _dev_drms(tsa, shape, (l,) * (d - 1), (r,) * (d - 1), ld, rd)
+    good = [orc.random_tt(shape, 10, rng) for _ in range(5)]
+    low = orc.random_tt(shape, 5, rng)
+    low = [np.concatenate([c, np.zeros((c.shape[0], c.shape[1], 10 - c.shape[2]))], axis=2) if k < d - 1 else c for k, c in enumerate(low)]
+    low = [np.concatenate([c, np.zeros((10 - c.shape[0], c.shape[1], c.shape[2]))], axis=0) if k > 0 else c for k, c in enumerate(low)]
+    cores = good[:2] + [low] + good[2:]                                  # same signature (TT-rank 10), numerical rank 5
+    before = dict(sketch_dispatch.robust_reruns)
+    got = tsa.orthogonal_sketch_batch([tsa.TensorTrain(c) for c in cores], (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+    reruns = sketch_dispatch.robust_reruns.get("orthogonal", 0) - before.get("orthogonal", 0)
+    assert reruns >= 1                                                   # (the batch's verdict, then orthogonal_sketch's own optimistic pass)
+    for k, (c, tt) in enumerate(zip(cores, got)):
+        if k == 2:
+            assert tt.error(tsa.TensorTrain(c), relative=True) < 1e-9      # exact recovery of the rank-5 tensor
+        else:
+            want, _ = orc.general_sketch("tt", c, ld, rd, "orthogonal")
+            _close([np.asarray(x) for x in tt.cores], want)
+    # mixed signatures / a dense tensor: one by one
+    other = orc.random_tt(shape, 7, rng)
+    mixed = [tsa.TensorTrain(good[0]), tsa.TensorTrain(other), tsa.DenseTensor(tsa.TensorTrain(good[1]).to_numpy())]
+    res = tsa.orthogonal_sketch_batch(mixed, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+    want, _ = orc.general_sketch("tt", good[0], ld, rd, "orthogonal")
+    _close([np.asarray(x) for x in res[0].cores], want)
+    assert len(res) == 3 and res[2].shape == shape
+    with pytest.raises(ValueError):
+        tsa.orthogonal_sketch_batch(mixed[:2], (l,) * (d - 1), (l,) * (d - 1))
+    assert tsa.orthogonal_sketch_batch([], l, r) == [] and tsa.hmt_sketch_batch([], r) == []
+    # default DRMs: one pair for the whole batch, returned
+    res, L, R = tsa.orthogonal_sketch_batch(mixed[:1] * 3, l, r, seed=5, return_drm=True)
+    assert type(L).__name__ == "TensorTrainDRM" and len(res) == 3
+    for a, b in zip(res[0].cores, res[2].cores):
+        assert np.array_equal(np.asarray(a), np.asarray(b))

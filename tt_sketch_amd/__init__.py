@@ -7,7 +7,7 @@ There is no CPU fallback: compute entry points raise if the library or a GPU is 
 """
 from .drm import ALL_DRM, DenseGaussianDRM, SparseGaussianDRM, SparseSignDRM, TensorTrainDRM
 from .sketch import (SketchedTensorTrain, assemble_sketched_tt, blocked_stream_sketch, hmt_sketch,
-                     orthogonal_sketch, stream_sketch, stream_sketch_batch)
+                     orthogonal_sketch, orthogonal_sketch_batch, hmt_sketch_batch, stream_sketch, stream_sketch_batch)
 from .sketch_container import SketchContainer
 from .sketch_dispatch import SketchMethod, general_sketch
 from .tensor import (CPTensor, DenseTensor, SparseTensor, Tensor, TensorSum, TensorTrain,
@@ -17,7 +17,7 @@ from .tt_svd import tt_svd
 __all__ = [
     "ALL_DRM", "DenseGaussianDRM", "SparseGaussianDRM", "SparseSignDRM", "TensorTrainDRM",
     "SketchedTensorTrain", "assemble_sketched_tt", "blocked_stream_sketch", "hmt_sketch",
-    "orthogonal_sketch", "stream_sketch", "stream_sketch_batch", "SketchContainer", "SketchMethod", "general_sketch",
+    "orthogonal_sketch", "orthogonal_sketch_batch", "hmt_sketch_batch", "stream_sketch", "stream_sketch_batch", "SketchContainer", "SketchMethod", "general_sketch",
     "CPTensor", "DenseTensor", "SparseTensor", "Tensor", "TensorSum", "TensorTrain", "TuckerTensor",
     "tt_svd",
 ]

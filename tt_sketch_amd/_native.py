@@ -104,6 +104,7 @@ def _bind(lib):
         "ttsk_dense_left_pass": [P, c_int64, c_int64, c_int64, c_int64, c_int64, I, P, P, P, P, P, P, P, P, I],
         "ttsk_orth_step_pinv": [P, c_int64, c_int64, P, c_int64, P, I],
         "ttsk_tt_orth_sketch": [I] + [POINTER(c_int64)] * 4 + [POINTER(P)] * 5 + [I],
+        "ttsk_tt_orth_sketch_batch": [I, I] + [POINTER(c_int64)] * 4 + [POINTER(P)] * 5 + [P, I],
         "ttsk_tt_assemble": [I] + [POINTER(c_int64)] * 3 + [POINTER(P)] * 4 + [I, I],
         "ttsk_comm_unique_id": [P], "ttsk_comm_init": [P, I, I],
         "ttsk_comm_allreduce_sum": [P, S, I], "ttsk_comm_reduce_sum": [P, S, I, I],
@@ -160,10 +161,10 @@ _STREAM_LAST = frozenset((
     "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_chain_step_wide", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
     "ttsk_fill_normal", "ttsk_fill_normal_many", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
     "ttsk_sparse_sort_mode", "ttsk_sparse_normal_table", "ttsk_sparse_sign_table", "ttsk_sparse_mode_order", "ttsk_sparse_mode_stream", "ttsk_sparse_gauss_pass", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
-    "ttsk_qr_thin", "ttsk_orth_step", "ttsk_orth_step_pinv", "ttsk_pinv_batch_deferred", "ttsk_pinv_batch", "ttsk_dense_first_pass", "ttsk_tt_orth_sketch", "ttsk_tt_assemble", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
+    "ttsk_qr_thin", "ttsk_orth_step", "ttsk_orth_step_pinv", "ttsk_pinv_batch_deferred", "ttsk_pinv_batch", "ttsk_dense_first_pass", "ttsk_tt_orth_sketch", "ttsk_tt_orth_sketch_batch", "ttsk_tt_assemble", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
 _BLOCKING = frozenset(("ttsk_h2d", "ttsk_d2h"))          # return only after their stream has drained
 _TWO_STREAMS = frozenset(("ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_tt_orth_sketch"))   # fork a helper on stream + 1, joined back
-_ALL_STREAMS = frozenset(("ttsk_tt_assemble",))           # fork every other library stream, all joined back
+_ALL_STREAMS = frozenset(("ttsk_tt_assemble", "ttsk_tt_orth_sketch_batch"))           # fork every other library stream, all joined back
 
 
 def sync_epoch() -> int:

@@ -197,6 +197,55 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
     return TTSK_OK;
 }
 
+// verdict of one tensor of a batch: move the stream's deferred flag to the tensor's slot and clear it
+__global__ void orth_take_flag_kernel(int *sticky, int *dst)
+{
+    if (threadIdx.x == 0) { *dst = *sticky; *sticky = 0; }
+}
+
+// `count` tensor trains of ONE signature against ONE pair of DRMs (sketch.py:292-301: further tensors are sketched with the
+// DRMs of the first): the sketches are independent chains of ~90 short, dependent launches each -- latency, not throughput
+// (0.07 of the matrix peak per call at C3) -- so tensor b runs on the stream pair (2 b mod 8, + 1) beside three others; the
+// library's streams are forked from `stream` and joined back into it.  dev_status[b] = 1 if a fast factorisation of tensor
+// b was rejected (the caller repeats that tensor on the robust path); the deferred flags of the streams used end up clear.
+int ttsk_tt_orth_sketch_batch(int count, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
+                              const double *const *X, const double *const *DL, const double *const *DR,
+                              double *const *cores_out, double *const *omega_out, int *dev_status, int stream)
+{
+    TTSK_STREAM(st, stream);
+    (void)st;
+    TTSK_ARG(count >= 1 && X && cores_out && dev_status, "ttsk_tt_orth_sketch_batch: bad argument");
+    TTSK_ARG(!DL || omega_out, "ttsk_tt_orth_sketch_batch: the orthogonal method needs omega_out");
+    int rc;
+    bool used[TTSK_NUM_STREAMS] = {};
+    const int lanes = TTSK_NUM_STREAMS / 2;
+    for (int b = 0; b < count; ++b) {
+        const int q = (stream + 2 * (b % lanes)) % TTSK_NUM_STREAMS, qa = (q + 1) % TTSK_NUM_STREAMS;
+        if (!used[q]) {
+            // the pair's first tensor: behind what `stream` has queued so far (the DRM cores may still be in the making).
+            // A flag left on the pair's stream by an earlier, unrelated call is not this batch's: cleared.
+            if (q != stream) { if ((rc = ttsk_stream_wait(q, stream)) < 0) return rc; }
+            if (qa != stream) { if ((rc = ttsk_stream_wait(qa, stream)) < 0) return rc; }
+            used[q] = used[qa] = true;
+        }
+        int *sticky = deferred_flag(q);
+        if (!sticky) return TTSK_ERR_HIP;
+        if (b < lanes && q != stream) hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), sticky, dev_status + b);
+        rc = ttsk_tt_orth_sketch(d, n, s, lt, rt, X + (size_t)b * d, DL, DR, cores_out + (size_t)b * d,
+                                 omega_out ? omega_out + (size_t)b * (d - 1) : nullptr, q);
+        if (rc < 0) {
+            for (int k = 0; k < TTSK_NUM_STREAMS; ++k)
+                if (used[k] && k != stream) (void)ttsk_stream_wait(stream, k);
+            return rc;
+        }
+        hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), sticky, dev_status + b);
+        TTSK_LAUNCH_CHECK();
+    }
+    for (int k = 0; k < TTSK_NUM_STREAMS; ++k)
+        if (used[k] && k != stream) { if ((rc = ttsk_stream_wait(stream, k)) < 0) return rc; }
+    return TTSK_OK;
+}
+
 // assemble_sketched_tt (sketch.py:400-443) as ONE call: C_mu = Psi_mu pinv(Omega_mu) ("right", direction = 0) or
 // pinv(Omega_{mu-1}) Psi_mu ("left", direction = 1).  The d - 1 (pseudo-inverse, product) pairs are independent: pair k
 // runs on library stream k mod nstreams -- fast attempt, the Jacobi kernel queued behind it with the attempt's verdict

@@ -77,24 +77,7 @@ def orthogonal_sketch(tensor: Tensor, left_rank: TTRank, right_rank: TTRank,
                       right_drm: Optional[DRM] = None, return_drm: bool = False):
     """Two-sided sketch with an orthogonalisation after every core; returns a TensorTrain
     (reference sketch.py:81-151).  Requires right_rank > left_rank elementwise."""
-    d = len(tensor.shape)
-    if not bool(np.all(np.array(left_rank) < np.array(right_rank))):
-        raise ValueError("The right rank needs to be larger than the left rank. "
-                         f"Left rank: {left_rank}, right rank: {right_rank}")
-    if seed is None:
-        seed = _fresh_seed()
-    ltype, rtype = _pick_types(left_drm_type, right_drm_type)
-    if left_drm is None:
-        left_rank = process_tt_rank(left_rank, tensor.shape, trim=True)
-        left_drm = ltype(left_rank, transpose=False, shape=tensor.shape, seed=seed)
-    elif left_drm.rank != left_rank:
-        raise ValueError(f"Left rank {left_rank} does not match the rank of the DRM {left_drm.rank}.")
-    if right_drm is None:
-        right_rank = process_tt_rank(right_rank, tensor.shape, trim=False)
-        right_drm = rtype(right_rank, transpose=True, shape=tensor.shape, seed=_right_seed(seed, d))
-    elif tuple(right_drm.rank[::-1]) != right_rank:
-        raise ValueError(
-            f"Right rank {right_rank} does not match the rank of the DRM {right_drm.rank}.")
+    left_drm, right_drm = _orth_drms(tensor, left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm)
     sketch = general_sketch(tensor, left_drm, right_drm, method=SketchMethod.orthogonal)
     sketched = TensorTrain(sketch.device_arrays()[0])     # cores stay in HBM (DevArray; np.asarray(core) copies out)
     return (sketched, left_drm, right_drm) if return_drm else sketched
@@ -177,6 +160,93 @@ def stream_sketch_batch(tensors: Sequence[Tensor], left_rank: TTRank, right_rank
         for t in tensors:
             out.append(stream_sketch(t, lrank, rrank, left_drm=left_drm, right_drm=right_drm))
     return (out, left_drm, right_drm) if return_drm else out
+
+
+ORTH_BATCH_SLICE = 16        # tensors per ttsk_tt_orth_sketch_batch call (four chains run at a time; outputs of a call share one buffer)
+
+
+def _orth_batch(tensors, left_drm, right_drm, method, one):
+    """the tensors through ``ttsk_tt_orth_sketch_batch`` in slices where that applies; ``one(t)``: the per-tensor call, for
+    everything else and for tensors whose fast factorisations were rejected (rank-deficient Omega, ill-conditioned
+    unfolding: the verdict comes back per tensor)"""
+    from . import tt_fused
+    from .sketch_dispatch import robust_reruns
+    out = []
+    for b0 in range(0, len(tensors), ORTH_BATCH_SLICE):
+        part = tensors[b0:b0 + ORTH_BATCH_SLICE]
+        res = tt_fused.try_orth_sketch_batch(part, left_drm, right_drm, method) if len(part) > 1 else None
+        if res is None:
+            out += [one(t) for t in part]
+            continue
+        outs, status = res
+        bad = status.get().view(np.int32)[:len(part)]
+        for t, (cores, _), rejected in zip(part, outs, bad):
+            if rejected:
+                robust_reruns[method.value] = robust_reruns.get(method.value, 0) + 1
+                out.append(one(t))
+            else:
+                out.append(TensorTrain(cores))
+    return out
+
+
+def orthogonal_sketch_batch(tensors: Sequence[Tensor], left_rank: TTRank, right_rank: TTRank, seed: Optional[int] = None,
+                            left_drm_type: Optional[Type[DRM]] = None, right_drm_type: Optional[Type[DRM]] = None,
+                            left_drm: Optional[DRM] = None, right_drm: Optional[DRM] = None, return_drm: bool = False):
+    """``[orthogonal_sketch(t, ...) for t in tensors]`` with ONE pair of DRMs (the setting of reference sketch.py:292-301;
+    the caller with many same-shaped inputs is tt_gmres.py:293-299).  TensorTrains of one signature with TensorTrainDRMs
+    run as concurrent chains on the device (``ttsk_tt_orth_sketch_batch``: a single sketch is ~90 dependent launches on
+    small operands, four of them side by side fill the gaps); anything else is one ``orthogonal_sketch`` per tensor."""
+    tensors = list(tensors)
+    if not tensors:
+        return ([], left_drm, right_drm) if return_drm else []
+    left_drm, right_drm = _orth_drms(tensors[0], left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm)
+    lrank, rrank = left_drm.rank, tuple(right_drm.rank[::-1])
+    one = lambda t: orthogonal_sketch(t, lrank, rrank, left_drm=left_drm, right_drm=right_drm)
+    out = _orth_batch(tensors, left_drm, right_drm, SketchMethod.orthogonal, one)
+    return (out, left_drm, right_drm) if return_drm else out
+
+
+def _orth_drms(tensor, left_rank, right_rank, seed, left_drm_type, right_drm_type, left_drm, right_drm):
+    """argument policy of ``orthogonal_sketch`` (reference sketch.py:99-140) without the sketch"""
+    d = len(tensor.shape)
+    if not bool(np.all(np.array(left_rank) < np.array(right_rank))):
+        raise ValueError("The right rank needs to be larger than the left rank. "
+                         f"Left rank: {left_rank}, right rank: {right_rank}")
+    if seed is None:
+        seed = _fresh_seed()
+    ltype, rtype = _pick_types(left_drm_type, right_drm_type)
+    if left_drm is None:
+        left_rank = process_tt_rank(left_rank, tensor.shape, trim=True)
+        left_drm = ltype(left_rank, transpose=False, shape=tensor.shape, seed=seed)
+    elif left_drm.rank != left_rank:
+        raise ValueError(f"Left rank {left_rank} does not match the rank of the DRM {left_drm.rank}.")
+    if right_drm is None:
+        right_rank = process_tt_rank(right_rank, tensor.shape, trim=False)
+        right_drm = rtype(right_rank, transpose=True, shape=tensor.shape, seed=_right_seed(seed, d))
+    elif tuple(right_drm.rank[::-1]) != right_rank:
+        raise ValueError(
+            f"Right rank {right_rank} does not match the rank of the DRM {right_drm.rank}.")
+    return left_drm, right_drm
+
+
+def hmt_sketch_batch(tensors: Sequence[Tensor], rank: TTRank, seed: Optional[int] = None,
+                     drm_type: Optional[Type[DRM]] = None, drm: Optional[DRM] = None, return_drm: bool = False):
+    """``[hmt_sketch(t, ...) for t in tensors]`` with ONE DRM; batched as ``orthogonal_sketch_batch``."""
+    tensors = list(tensors)
+    if not tensors:
+        return ([], drm) if return_drm else []
+    if seed is None:
+        seed = _fresh_seed()
+    if drm is None:
+        drm_type = TensorTrainDRM if drm_type is None else drm_type
+        rank = process_tt_rank(rank, tensors[0].shape, trim=True)
+        drm = drm_type(rank, transpose=True, shape=tensors[0].shape, seed=seed)
+    elif tuple(drm.rank[::-1]) != rank:
+        raise ValueError(f"Right rank {rank} does not match the rank of the DRM {drm.rank}.")
+    rrank = tuple(drm.rank[::-1])
+    one = lambda t: hmt_sketch(t, rrank, drm=drm)
+    out = _orth_batch(tensors, None, drm, SketchMethod.hmt, one)
+    return (out, drm) if return_drm else out
 
 
 class SketchedTensorTrain(Tensor):

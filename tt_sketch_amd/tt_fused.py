@@ -208,3 +208,58 @@ def try_orth_sketch(tensor, left_drm, right_drm, method) -> Optional[Tuple[list,
     except nat.TtskUnsupported:
         return None
     return cores, Omega
+
+
+def try_orth_sketch_batch(tensors, left_drm, right_drm, method):
+    """``try_orth_sketch`` for tensor trains of ONE signature through ``ttsk_tt_orth_sketch_batch`` (the sketches run as
+    concurrent chains on the library's streams): a list of (cores, Omega) per tensor and an int32 device array of verdicts
+    (1 = repeat that tensor on the robust path), or None if the batch path does not apply."""
+    from .sketch_dispatch import SketchMethod
+    if method not in (SketchMethod.orthogonal, SketchMethod.hmt) or not tensors:
+        return None
+    if any(type(t) is not TensorTrain for t in tensors):
+        return None
+    first = tensors[0]
+    if any(tuple(t.shape) != tuple(first.shape) or tuple(t.rank) != tuple(first.rank) for t in tensors):
+        return None
+    orth = method == SketchMethod.orthogonal
+    if type(right_drm) is not TensorTrainDRM or not right_drm.transpose:
+        return None
+    if orth and (type(left_drm) is not TensorTrainDRM or left_drm.transpose):
+        return None
+    d = len(first.shape)
+    drms = [right_drm] + ([left_drm] if orth else [])
+    if d < 2 or any(len(m.cores) != d - 1 or tuple(m.shape) != tuple(first.shape) for m in drms):
+        return None
+    if any(tuple(m.rank_min) != (0,) * (d - 1) or tuple(m.rank_max) != tuple(m.true_rank) for m in drms):
+        return None
+    B = len(tensors)
+    arr = lambda v: (_I64 * len(v))(*[int(x) for x in v])
+    P = ctypes.c_void_p
+    n, s = arr(first.shape), arr((1,) + tuple(first.rank) + (1,))
+    rt = arr((1,) + tuple(right_drm.true_rank))
+    keep = [[c.contiguous() for t in tensors for c in t.dev_cores()], [c.contiguous() for c in right_drm.dev_cores()]]
+    X = (P * (B * d))(*[c.ptr for c in keep[0]])
+    DR = (P * (d - 1))(*[c.ptr for c in keep[1]])
+    right_rank = tuple(right_drm.rank[::-1])
+    if orth:
+        lt = arr((1,) + tuple(left_drm.true_rank))
+        keep.append([c.contiguous() for c in left_drm.dev_cores()])
+        DL = (P * (d - 1))(*[c.ptr for c in keep[2]])
+        out_rank = tuple(left_drm.rank)
+        om_shapes = [(out_rank[mu], right_rank[mu]) for mu in range(d - 1)]
+    else:
+        lt, DL, om_shapes = None, None, []
+        out_rank = right_rank
+    kr = (1,) + out_rank + (1,)
+    per = [(kr[mu], first.shape[mu], kr[mu + 1]) for mu in range(d)] + om_shapes
+    arrs = _carve(per * B)
+    outs = [(arrs[b * len(per):b * len(per) + d], arrs[b * len(per) + d:(b + 1) * len(per)]) for b in range(B)]
+    cores = (P * (B * d))(*[c.ptr for o in outs for c in o[0]])
+    om = (P * (B * (d - 1)))(*[c.ptr for o in outs for c in o[1]]) if orth else None
+    status = DevArray.zeros(((B + 1) // 2,), dtype=np.int64)         # B int32 verdicts
+    try:
+        nat.call("ttsk_tt_orth_sketch_batch", B, d, n, s, lt, rt, X, DL, DR, cores, om, P(status.ptr), 0)
+    except nat.TtskUnsupported:
+        return None
+    return outs, status
