@@ -219,31 +219,37 @@ int ttsk_tt_orth_sketch_batch(int count, int d, const int64_t *n, const int64_t 
     int rc;
     bool used[TTSK_NUM_STREAMS] = {};
     const int lanes = TTSK_NUM_STREAMS / 2;
-    for (int b = 0; b < count; ++b) {
-        const int q = (stream + 2 * (b % lanes)) % TTSK_NUM_STREAMS, qa = (q + 1) % TTSK_NUM_STREAMS;
-        if (!used[q]) {
-            // the pair's first tensor: behind what `stream` has queued so far (the DRM cores may still be in the making).
-            // A flag left on the pair's stream by an earlier, unrelated call is not this batch's: cleared.
-            if (q != stream) { if ((rc = ttsk_stream_wait(q, stream)) < 0) return rc; }
-            if (qa != stream) { if ((rc = ttsk_stream_wait(qa, stream)) < 0) return rc; }
-            used[q] = used[qa] = true;
-        }
+    auto pair_of = [&](int b) { return (stream + 2 * (b % lanes)) % TTSK_NUM_STREAMS; };
+    auto join_all = [&]() {
+        int worst = TTSK_OK;
+        for (int k = 0; k < TTSK_NUM_STREAMS; ++k)
+            if (used[k] && k != stream) { const int r = ttsk_stream_wait(stream, k); if (r < 0) worst = r; }
+        return worst;
+    };
+    // the pairs' streams: behind what `stream` has queued so far (the DRM cores may still be in the making).  A flag left on
+    // a pair's stream by an earlier, unrelated call is not this batch's: cleared.
+    for (int b = 0; b < count && b < lanes; ++b) {
+        const int q = pair_of(b), qa = (q + 1) % TTSK_NUM_STREAMS;
+        if (q != stream) { if ((rc = ttsk_stream_wait(q, stream)) < 0) return rc; }
+        if (qa != stream) { if ((rc = ttsk_stream_wait(qa, stream)) < 0) return rc; }
+        used[q] = used[qa] = true;
         int *sticky = deferred_flag(q);
         if (!sticky) return TTSK_ERR_HIP;
-        if (b < lanes && q != stream) hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), sticky, dev_status + b);
-        rc = ttsk_tt_orth_sketch(d, n, s, lt, rt, X + (size_t)b * d, DL, DR, cores_out + (size_t)b * d,
-                                 omega_out ? omega_out + (size_t)b * (d - 1) : nullptr, q);
-        if (rc < 0) {
-            for (int k = 0; k < TTSK_NUM_STREAMS; ++k)
-                if (used[k] && k != stream) (void)ttsk_stream_wait(stream, k);
-            return rc;
-        }
-        hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), sticky, dev_status + b);
-        TTSK_LAUNCH_CHECK();
+        if (q != stream) hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), sticky, dev_status + b);
     }
-    for (int k = 0; k < TTSK_NUM_STREAMS; ++k)
-        if (used[k] && k != stream) { if ((rc = ttsk_stream_wait(stream, k)) < 0) return rc; }
-    return TTSK_OK;
+    auto one = [&](int b) -> int {
+        const int q = pair_of(b);
+        int r = ttsk_tt_orth_sketch(d, n, s, lt, rt, X + (size_t)b * d, DL, DR, cores_out + (size_t)b * d,
+                                    omega_out ? omega_out + (size_t)b * (d - 1) : nullptr, q);
+        if (r < 0) return r;
+        hipLaunchKernelGGL(orth_take_flag_kernel, dim3(1), dim3(64), 0, stream_of(q), deferred_flag(q), dev_status + b);
+        return hipGetLastError() == hipSuccess ? TTSK_OK : TTSK_ERR_HIP;
+    };
+    // (Queuing the tensors of each stream pair from a thread of their own was measured: 0.65 against 0.67 ms per tensor at C3,
+    // batch 8 -- the host's 0.4 ms per sketch is not what binds, the device-side sum of ~90 small kernels per sketch is; not kept.)
+    for (int b = 0; b < count; ++b)
+        if ((rc = one(b)) < 0) { (void)join_all(); return rc; }
+    return join_all();
 }
 
 // assemble_sketched_tt (sketch.py:400-443) as ONE call: C_mu = Psi_mu pinv(Omega_mu) ("right", direction = 0) or
