@@ -837,7 +837,7 @@ def bench_c4(args, job):
     # sign DRMs, a few sketches each; "ms_per_column" = time / DRM columns made per nonzero, the in-cover row first
     cover = []
     G, S = tsa.SparseGaussianDRM, tsa.SparseSignDRM
-    for name, mk in [("gaussian l=10 r=15 (in cover)", lambda: (G(l, shape, False, seed=3), G(r, shape, True, seed=4))),
+    for name, mk in [] if not getattr(args, "cover", False) else [("gaussian l=10 r=15 (in cover)", lambda: (G(l, shape, False, seed=3), G(r, shape, True, seed=4))),
                      ("gaussian l=17 r=17", lambda: (G(17, shape, False, seed=3), G(17, shape, True, seed=4))),
                      ("gaussian l=24 r=24", lambda: (G(24, shape, False, seed=3), G(24, shape, True, seed=4))),
                      ("sign l=10 r=15", lambda: (S(l, shape, False, seed=3), S(r, shape, True, seed=4))),
@@ -848,6 +848,7 @@ def bench_c4(args, job):
         cover.append(dict(drm=name, ms=med, columns_per_nonzero=cols, ms_per_column=med / max(cols, 1)))
     for c in cover:
         c["per_column_vs_in_cover"] = c["ms_per_column"] / cover[0]["ms_per_column"]
+    cover = cover or None
     cpu = None
     if not args.no_cpu and job.world == 1:
         # the reference's Psi is O(n_mu nnz) boolean masks (sparse_sketch.py:18,60): nnz = 2e5 takes seconds, 1e7 minutes
@@ -905,6 +906,20 @@ def bench_c3_solves(args, job, reps=7):
                          roofline=dict(bound="mfma", achieved=gf / med, peak=PEAK_F64_MFMA_TF, unit="TFLOP/s", frac=gf / med / PEAK_F64_MFMA_TF,
                                        traffic=None, what="sketch products + pinv-apply + thin QR flops / wall time of one API call incl. DRM "
                                                           "sampling: a chain of ~80 dependent launches on 10^4-row operands (ttsk_tt_orth_sketch), latency-bound"))
+    # same-signature tensors against ONE pair of DRMs: concurrent chains on the library's stream pairs
+    tts = [device_tt(shape, S_IN, 78 + b) for b in range(8)]
+    ldrm = tsa.TensorTrainDRM(L_RANK, shape, False, seed=1)
+    rdrm = tsa.TensorTrainDRM(R_RANK, shape, True, seed=2)
+    hdrm = tsa.TensorTrainDRM(L_RANK, shape, True, seed=3)
+    lr, rr = (L_RANK,) * (D - 1), (R_RANK,) * (D - 1)
+    for name, fn, single in (("orthogonal_sketch_batch8", lambda: tsa.orthogonal_sketch_batch(tts, lr, rr, left_drm=ldrm, right_drm=rdrm),
+                              lambda: tsa.orthogonal_sketch(tts[0], lr, rr, left_drm=ldrm, right_drm=rdrm)),
+                             ("hmt_sketch_batch8", lambda: tsa.hmt_sketch_batch(tts, lr, drm=hdrm), lambda: tsa.hmt_sketch(tts[0], lr, drm=hdrm))):
+        best, med = timed_calls(nat, fn, reps=reps)
+        _, one = timed_calls(nat, single, reps=reps)
+        out[name] = dict(ms=med, best_ms=best, ms_per_tensor=med / len(tts), one_call_with_the_same_drms_ms=one, tensors=len(tts),
+                         what="8 TTs of the C3 signature, DRMs given (no sampling in the timed region): ttsk_tt_orth_sketch_batch")
+    del tts
     if not args.no_cpu and job.world == 1 and job.rank == 0:
         import __graft_entry__ as ge
         ge.build_oracle()
@@ -932,7 +947,7 @@ def compact(line):
         return None
     roof = {k: line["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes",
                                                   "hbm_gbs", "hbm_frac", "executed_gflop", "mfma_frac_of_reference_count", "mfma_frac_of_algorithmic_flops",
-                                                  "classes", "first_call_ms", "measured_valu_gsamples")
+                                                  "classes", "first_call_ms", "measured_valu_gsamples", "cover")
             if line.get("roofline") and k in line["roofline"]}
     cpu = line.get("cpu_baseline")
     if cpu:
@@ -948,6 +963,7 @@ def run_extras(args, job):
     extra = {}
     sub = copy.copy(args)
     sub.steps, sub.warmup = 5, 2
+    sub.cover = True
     for name, fn in (("c5", bench_c5), ("c4", bench_c4), ("c2", bench_c2), ("c2_gaussian", lambda a, j: bench_c2(a, j, gaussian=True))):
         t0 = time.perf_counter()
         # (c2: a sketch is 4 ms and its first calls grow the library's scratch arenas by 1.3 GB -- a few more of both)
@@ -997,6 +1013,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", action="store_true",
                     help="--scaling strong: also print norm / probe of the sketch of the whole job (identical for every N)")
+    ap.add_argument("--cover", action="store_true", help="--config c4: also time the shapes just outside the round-3 cover (wider / sign DRMs); "
+                                                         "always on in the default run's c4 sub-record")
     ap.add_argument("--no-extra", action="store_true", help="default config only: skip the c2 / c4 / c5 / solves / ref150 sub-records")
     ap.add_argument("--batch", type=int, default=32, help="TTs per batched pass (ttsk_tt_sketch_batch; 32 = 8 workgroups x 25 slices per tensor in the fused chain step)")
     ap.add_argument("--inflight", type=int, default=2,
