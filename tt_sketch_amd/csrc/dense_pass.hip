@@ -72,6 +72,8 @@ struct DensePass {
     double *slab;          // [workgroup][NB][4 TP + SP][64]: the accumulators as the lanes hold them
     int nt, nqc;           // t ranges (T / 16), q chunks (a multiple of 8)
     int64_t zblock;        // first mode beyond 64: blocks of 64 values of b, blockIdx = block * nt * nqc + ...; block k's partial Z at Z + k * zblock
+    int split;             // 1: two kinds of workgroups per (t range, q range, block): kind k takes columns [k p_half, ..) of P / U and
+    int p_half, z_half;    //    rows [k z_half, ..) of Z -- each reads the tile (the second read from L2 / MALL); 0: one kind takes all
     int dbg;               // diagnostics (TTSK_DP_DBG): 1 = no tile loads after the first, 2 = no Z stores, 4 = no rotated start, 8 = loads and stores of a tile in one burst
 };
 
@@ -94,7 +96,11 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 
     const int tid = threadIdx.x, lane = tid & 63, x16 = lane & 15, kq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = blockIdx.x, per_block = a.nt * a.nqc, bb = id / per_block, idl = id - bb * per_block;
+    // kinds alternate in groups of 8 consecutive ids: both kinds of a (t range, q range) on one XCD, one dispatch round apart
+    const int kind = a.split ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int id = a.split ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int p_off = kind * a.p_half, z_off = kind * a.z_half;
+    const int per_block = a.nt * a.nqc, bb = id / per_block, idl = id - bb * per_block;
     // the nt workgroups that share the 512-byte rows of a q range sit on one XCD (ids 8 apart) next to each other in time
     const int tr = (idl >> 3) % a.nt, qc = (idl & 7) + 8 * (idl / (8 * a.nt));
     const int t0 = 16 * tr;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 
     for (int e = tid; e < NB * CW; e += 512) {
         const int b = e / CW, c = e - CW * b;
-        const double v = c < a.ll ? a.C[((int64_t)bb * NB + b) * a.ll + c] : 0.0;
+        const double v = z_off + c < a.ll ? a.C[((int64_t)bb * NB + b) * a.ll + z_off + c] : 0.0;
         if (c < 16 * ZT) Cf[((c >> 4) * NB + b) * 16 + (c & 15)] = v;
         else Cs[(((c - 16 * ZT) >> 2) * NB + b) * 4 + (c & 3)] = v;
     }
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     const int xrow = lane >> 3, xcol = 2 * (lane & 7);
     const uint32_t xoff0 = (uint32_t)((xrow * a.T + xcol) * 8), xoff1 = (uint32_t)(((xrow ^ 1) * a.T + xcol) * 8);
     const int pU = 64 * w + lane, prow = (pU / DP_PU) & 7, ppair = pU % DP_PU;
-    const uint32_t poff = (uint32_t)((prow * a.pr + (2 * ppair + 2 <= a.pr ? 2 * ppair : 0)) * 8);
+    const uint32_t poff = (uint32_t)((prow * a.pr + (p_off + 2 * ppair + 2 <= a.pr ? p_off + 2 * ppair : 0)) * 8);
     const char *xbase = (const char *)a.X + (((int64_t)bb * NB + w * NBW) * a.sb + t0) * 8;
     // (one chunk at a time: `issue_x(tile offset, image, u)` is spread over the steps of a tile -- eight load instructions in a
     // row from each of eight waves stall every wave's instruction stream, and with it the matrix pipes, behind the address unit:
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         issue_p(it, buf);
     };
 
-    v4d acc[NBW][TP];
+    v4d acc[NBW][TP > 0 ? TP : 1];
     double accs[NBW][SP > 0 ? SP : 1];
 #pragma unroll
     for (int bi = 0; bi < NBW; ++bi) {
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     }
 
     // Z: wave w chains row q0 + w of the tile over all b; the row is stored while the next tile is computed on
-    v4d zp[ZT];
+    v4d zp[ZT > 0 ? ZT : 1];
     double zps[ZS > 0 ? ZS : 1];
 #pragma unroll
     for (int zt = 0; zt < ZT; ++zt)
@@ -163,16 +169,19 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     for (int zs = 0; zs < (ZS > 0 ? ZS : 1); ++zs) zps[zs] = 0.0;
     const int64_t zs_row = (int64_t)a.Q * a.T;
     const uint32_t zoff = (uint32_t)((kq * zs_row + x16) * 8);          // 3 Q T doubles at most: the host checks the range
+    const int z_end = a.split && kind == 0 ? a.z_half : a.ll;          // rows of Z this kind owns: [z_off, z_end)
     auto store_z = [&](int it) {
         const int64_t at = uniform_i64(((int64_t)bb * a.zblock + ((int64_t)it * 8 + w) * a.T + t0) * 8);
 #pragma unroll
         for (int zt = 0; zt < ZT; ++zt)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (16 * zt + kq + 4 * j < a.ll) *(double *)((char *)a.Z + uniform_i64(at + (16 * zt + 4 * j) * zs_row * 8) + zoff) = zp[zt][j];
+                if (z_off + 16 * zt + kq + 4 * j < z_end)
+                    *(double *)((char *)a.Z + uniform_i64(at + (z_off + 16 * zt + 4 * j) * zs_row * 8) + zoff) = zp[zt][j];
 #pragma unroll
         for (int zs = 0; zs < ZS; ++zs)
-            if (16 * ZT + 4 * zs + kq < a.ll) *(double *)((char *)a.Z + uniform_i64(at + (16 * ZT + 4 * zs) * zs_row * 8) + zoff) = zps[zs];
+            if (z_off + 16 * ZT + 4 * zs + kq < z_end)
+                *(double *)((char *)a.Z + uniform_i64(at + (z_off + 16 * ZT + 4 * zs) * zs_row * 8) + zoff) = zps[zs];
     };
 
     // The range is walked from a start that differs from workgroup to workgroup (the same for the nt workgroups that share
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         // first matrix instruction of step s: the compiler puts lgkmcnt(0) in front of a step's first use, so the reads must
         // be neither younger than that wait nor right behind it; the scheduling barrier per step keeps that order -- left
         // alone, the compiler hoists every read of the tile to the front and spills the accumulators.
-        v4d z[ZT];
+        v4d z[ZT > 0 ? ZT : 1];
         double zs[ZS > 0 ? ZS : 1];
 #pragma unroll
         for (int zt = 0; zt < ZT; ++zt)
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
         const double *xz = xb + kq * 128 + (w ^ (kq & 1)) * 16 + x16;
         const double *cf = Cf + kq * 16 + x16, *cs = Cs + kq * 4 + (x16 & 3);
         const double *pr = pb + kq * DP_PROW + x16, *prs = pb + kq * DP_PROW + 16 * TP + (x16 & 3);
-        double pf[TP], ps[SP > 0 ? SP : 1], cff[ZT], csf[ZS > 0 ? ZS : 1];
+        double pf[TP > 0 ? TP : 1], ps[SP > 0 ? SP : 1], cff[ZT > 0 ? ZT : 1], csf[ZS > 0 ? ZS : 1];
 #pragma unroll
         for (int p = 0; p < TP; ++p) pf[p] = pr[16 * p];
 #pragma unroll
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 #pragma unroll
         for (int s = 0; s < 2 * NBW; ++s) {
             const int bi = s % NBW;
-            double xf_n = 0.0, xz_n = 0.0, pf_n[TP], ps_n[SP > 0 ? SP : 1], cf_n[ZT], cs_n[ZS > 0 ? ZS : 1];
+            double xf_n = 0.0, xz_n = 0.0, pf_n[TP > 0 ? TP : 1], ps_n[SP > 0 ? SP : 1], cf_n[ZT > 0 ? ZT : 1], cs_n[ZS > 0 ? ZS : 1];
 #pragma unroll
             for (int p = 0; p < TP; ++p) pf_n[p] = pf[p];
 #pragma unroll
@@ -245,8 +254,8 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
                     for (int p = 0; p < SP; ++p) ps_n[p] = prs[4 * jn * DP_PROW + 4 * p];
                 }
             }
-            acc[bi][0] = mfma16(xf, pf[0], acc[bi][0]);
-            z[0] = mfma16(cff[0], xzf, z[0]);
+            if constexpr (TP > 0) acc[bi][0] = mfma16(xf, pf[0], acc[bi][0]);
+            if constexpr (ZT > 0) z[0] = mfma16(cff[0], xzf, z[0]);
 #pragma unroll
             for (int p = 1; p < TP; ++p) acc[bi][p] = mfma16(xf, pf[p], acc[bi][p]);
 #pragma unroll
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 
     // the accumulators as they are: [b][slot][lane], slot = 4 * tile + register, 4 TP + strip
     constexpr int SL = 4 * TP + SP;
-    double *out = a.slab + ((int64_t)id * NB + w * NBW) * (SL * 64) + lane;
+    double *out = a.slab + (((int64_t)kind * gridDim.x / (a.split ? 2 : 1) + id) * NB + w * NBW) * (SL * 64) + lane;
 #pragma unroll
     for (int bi = 0; bi < NBW; ++bi) {
 #pragma unroll
@@ -308,7 +317,8 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
 }
 
 // U[b][p][t] = sum over the q chunks; one thread per accumulator element of a t range
-__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int TP, int SP, int nt, int nqc, int nbb, int T, int r, double *U)
+__global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int NB, int TP, int SP, int nt, int nqc, int nbb, int T, int r, double *U,
+                                                         int p_off, int pcount)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int sl64 = (4 * TP + SP) * 64, per = NB * sl64;
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void dense_pass_reduce(const double *slab, int
         p = 16 * TP + 4 * (slot - 4 * TP) + (l & 3);
         t = 4 * ((l >> 2) & 3) + (l >> 4);
     }
-    if (p < r) U[(((int64_t)bb * NB + b) * r + p) * T + 16 * tr + t] = s;
+    if (p < pcount) U[(((int64_t)bb * NB + b) * r + p_off + p) * T + 16 * tr + t] = s;
 }
 
 // Z = sum of the blocks' partial Z (first mode beyond 64)
@@ -388,18 +398,25 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     }
     TTSK_STREAM(st, stream);
     const int nt = (int)(T / 16);
-    // accumulator shapes: U as TP tiles + SP strips of columns, Z as ZT tiles + ZS strips of rows; blocks of 64 values of b where
-    // the registers allow it (the C2 shape), of 32 otherwise
-    const int ushape = r <= 40 ? 0 : r <= 48 ? 1 : 2, zshape = ll <= 20 ? 0 : 1;
-    const int TP = ushape == 0 ? 2 : ushape == 1 ? 3 : 4, SP = ushape == 0 ? 2 : 0;
-    const int NB = (ushape == 0 && zshape == 0 && !(n0 & 63)) ? 64 : 32, nbb = (int)(n0 / NB);
+    // accumulator shapes: U as TP tiles + SP strips of columns, Z as ZT tiles + ZS strips of rows.  Up to 40 / 20: one kind of
+    // workgroup, blocks of 64 values of b (the C2 shape).  Beyond, with whole blocks of 64: TWO kinds of workgroups, each with
+    // half the columns of U and half the rows of Z -- the accumulators of all 64 b fit, Z needs no partial sums over blocks
+    // of b, the matrix work stays proportional to the ranks, and the tile is read twice, the kinds of a (t range, q range) one
+    // dispatch round apart on one XCD.  Otherwise (first mode a multiple of 32 only): blocks of 32 with wider accumulators.
+    const bool split = !(n0 & 63) && (r > 40 || ll > 20);
+    const int p_half = split ? (int)((r + 1) / 2 + 3) / 4 * 4 : 0, z_half = split ? (int)((ll + 1) / 2 + 3) / 4 * 4 : 0;
+    const int ushape = split ? (p_half <= 24 ? 3 : 4) : r <= 40 ? 0 : r <= 48 ? 1 : 2;
+    const int zshape = split ? (z_half <= 12 ? 2 : 3) : ll <= 20 ? 0 : 1;
+    const int TP = ushape == 0 ? 2 : ushape == 1 ? 3 : ushape == 2 ? 4 : ushape == 3 ? 1 : 2, SP = ushape == 0 || ushape == 3 ? 2 : 0;
+    const int NB = (split || (ushape == 0 && zshape == 0 && !(n0 & 63))) ? 64 : 32, nbb = (int)(n0 / NB);
+    const int kinds = split ? 2 : 1;
     // q ranges: about 256 workgroups for one block of b, about 1024 over all blocks otherwise (several rounds over the CUs even
     // out the ranges); a multiple of 8, and not more than there are tiles
     int64_t nqc = 8 * std::max<int64_t>(1, (nbb == 1 ? 32 : (128 + nbb * nt / 2) / (nbb * nt)) / (nbb == 1 ? nt : 1));
     static const int nqc_env = [] { const char *e = getenv("TTSK_DP_NQC"); return e ? atoi(e) : 0; }();   // A/B runs
     if (nqc_env > 0 && nbb > 1) nqc = 8 * cdiv(nqc_env, 8);
     nqc = std::min<int64_t>(nqc, 8 * cdiv(Q / 8, 8));          // at least one tile for most chunks
-    const int64_t grid = (int64_t)nbb * nt * nqc;
+    const int64_t grid1 = (int64_t)nbb * nt * nqc, grid = grid1 * kinds;
     const int64_t sl64 = (4 * TP + SP) * 64;
     // partial results beyond 4 GB (many blocks of a large operand): not this kernel's case -- the caller forms the products separately
     if ((nbb > 1 && (int64_t)nbb * ll * Q * T * 8 > (4ll << 30)) || grid * NB * sl64 * 8 > (4ll << 30)) {
@@ -429,17 +446,25 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
 #else
     constexpr int dbg = 0;
 #endif
-    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, (int)pr, zout, slab, nt, (int)nqc, zblock, dbg};
+    DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, (int)pr, zout, slab, nt, (int)nqc, zblock, split ? 1 : 0, p_half, z_half, dbg};
     if (prof_on()) prof_open_named(st, PROF_SOLVE, 0.0, "dense_pass");
     int rc;
-    if (NB == 64) rc = dense_pass_launch<8, 2, 2, 1, 1>(a, grid, st);
+    if (split) {
+        if (ushape == 3) rc = zshape == 2 ? dense_pass_launch<8, 1, 2, 0, 3>(a, grid, st) : dense_pass_launch<8, 1, 2, 1, 0>(a, grid, st);
+        else rc = zshape == 2 ? dense_pass_launch<8, 2, 0, 0, 3>(a, grid, st) : dense_pass_launch<8, 2, 0, 1, 0>(a, grid, st);
+    } else if (NB == 64) rc = dense_pass_launch<8, 2, 2, 1, 1>(a, grid, st);
     else if (ushape == 0) rc = zshape == 0 ? dense_pass_launch<4, 2, 2, 1, 1>(a, grid, st) : dense_pass_launch<4, 2, 2, 2, 0>(a, grid, st);
     else if (ushape == 1) rc = zshape == 0 ? dense_pass_launch<4, 3, 0, 1, 1>(a, grid, st) : dense_pass_launch<4, 3, 0, 2, 0>(a, grid, st);
     else rc = zshape == 0 ? dense_pass_launch<4, 4, 0, 1, 1>(a, grid, st) : dense_pass_launch<4, 4, 0, 2, 0>(a, grid, st);
     if (rc != TTSK_OK) { set_error("ttsk_dense_first_pass: launch failed"); return rc; }
     const int64_t elems = (int64_t)NB * sl64 * nt * nbb;
-    hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab, NB, TP, SP, nt, (int)nqc, nbb, (int)T, (int)r, U);
-    TTSK_LAUNCH_CHECK();
+    for (int k = 0; k < kinds; ++k) {
+        const int p_off = k * p_half, pcount = split ? (k == 0 ? p_half : (int)r - p_half) : (int)r;
+        if (pcount <= 0) continue;
+        hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab + (size_t)k * grid1 * NB * sl64, NB, TP, SP, nt,
+                           (int)nqc, nbb, (int)T, (int)r, U, p_off, pcount);
+        TTSK_LAUNCH_CHECK();
+    }
     if (nbb > 1) {
         const int64_t pairs = zblock / 2;               // Q T is a multiple of 128
         hipLaunchKernelGGL(dense_pass_zsum, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, st, (const double2 *)zout, nbb, pairs, (double2 *)Z);
