@@ -733,6 +733,14 @@ def bench_c2(args, job, gaussian=False):
                    sample=f"oracle general_sketch of a dense d=5 n=32 tensor (268 MB = 1/32 of C2), {'DenseGaussianDRM' if gaussian else 'TensorTrainDRM'} l=20 r=40, "
                           f"DRMs pre-built, one run (~1 s); {CPU_THREADS} BLAS threads")
         del Xs
+    # just outside the round-3 cover of the one-pass kernel (left rank <= 20, even right rank <= 40): the same tensor, wider DRMs
+    cover = None
+    if not gaussian and getattr(args, "cover", False):
+        cover = [dict(drm="TensorTrainDRM l=20 r=40 (in cover)", ms=1e3 * t_step)]
+        for lw, rw in ((21, 42), (20, 41), (32, 64)):
+            lw_drm, rw_drm = tsa.TensorTrainDRM(lw, shape, False, seed=1), tsa.TensorTrainDRM(rw, shape, True, seed=2)
+            _, med = timed_calls(nat, lambda: tsa.general_sketch(T, lw_drm, rw_drm, tsa.SketchMethod.streaming), reps=3)
+            cover.append(dict(drm=f"TensorTrainDRM l={lw} r={rw}", ms=med, vs_in_cover=med / (1e3 * t_step)))
     base = dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f64", data="synthetic", cpu_baseline=cpu)
@@ -770,7 +778,7 @@ def bench_c2(args, job, gaussian=False):
                                    "reference's formulation) / wall time of one sketch against the fp64 matrix peak; hbm_*: the 8.59 GB that must "
                                    "move (the tensor once; no DRM matrix beyond 84 MB is formed) / the same time; counter traffic also holds the "
                                    "first left product written and read once (2 x 2.7 GB) and the partial sums",
-                              unfused_77GB_rate_gbs=unfused / t_step * 1e-9))
+                              unfused_77GB_rate_gbs=unfused / t_step * 1e-9, cover=cover))
     return base
 
 
