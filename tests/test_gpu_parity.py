@@ -1069,6 +1069,8 @@ def test_sparse_fused_passes_vs_oracle_and_generator_path(tsa, case, monkeypatch
     ((300, 7, 250, 9), 9000, ("s", 16, 3, 11, 9), ("g", 13, 2, 15, None)),                # a slice of a sign row; mixed pair
     ((300, 7, 250, 9), 9000, ("g", 20, 1, 21, None), ("s", 32, 5, 30, 32)),               # mixed pair, wide
     ((9, 11), 60, ("s", 4, 0, 4, 1), ("s", 32, 0, 32, 7)),
+    ((200, 150, 100, 120, 300), 40000, ("g", 10, 0, 10, None), ("g", 24, 0, 24, None)),   # one side inside 16 columns: tiles beyond it are skipped
+    ((40, 30, 20, 25, 35), 9000, ("g", 28, 0, 28, None), ("s", 12, 0, 12, 4)),
 ])
 def test_sparse_fused_wide_and_sign_factors_vs_oracle(tsa, case, monkeypatch):
     """the one-pass-per-mode sparse sketch beyond 16 columns per factor (2 x 2 matrix tiles) and with

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             // every nonzero of the tile belongs to the running slice (all but one tile in ~10^3 at C4): no slice test per
             // k-block, the validity bits from the ballot of stage (1), nothing but loads and matrix instructions in the loop
             constexpr int SG_UNR = NT == 1 ? 8 : 2;
-            auto run = [&](auto with_om) {
+            auto run = [&](auto with_om, auto all_tiles) {
+                constexpr bool every = NT == 1 || decltype(all_tiles)::value;
 #pragma unroll SG_UNR
                 for (int b = 0; b < SG_T / 4; ++b) {
                     const int e = 4 * b + kq;
@@ -312,14 +313,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
                     for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
                         for (int tb = 0; tb < NT; ++tb) {
+                            // (a tile wholly beyond a factor's width -- a factor of <= 16 columns beside a wider one -- is skipped)
                             if constexpr (decltype(with_om)::value)
-                                accO[ta][tb] = mfma16(a.c_left ? cv[ta] * rv[e] : av[ta], a.c_left ? bv[tb] : cv[tb], accO[ta][tb]);
-                            accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
+                                if (every || (16 * ta < wOl && 16 * tb < wOr))
+                                    accO[ta][tb] = mfma16(a.c_left ? cv[ta] * rv[e] : av[ta], a.c_left ? bv[tb] : cv[tb], accO[ta][tb]);
+                            if (every || (16 * ta < wA && 16 * tb < wB)) accP[ta][tb] = mfma16(av[ta], bv[tb], accP[ta][tb]);
                         }
                 }
             };
-            if (a.has_om) run(std::true_type{});
-            else run(std::false_type{});
+            // (NT = 2 with every factor beyond 16 columns: no tile to skip, no tests in the loop)
+            const bool full = NT == 1 || (wA > 16 && wB > 16 && (!a.has_om || (wOl > 16 && wOr > 16)));
+            if (a.has_om) { if (full) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+            else { if (full) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
         } else {
 #pragma unroll 1
             for (int b = 0; b < SG_T / 4; ++b) {
