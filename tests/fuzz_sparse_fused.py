@@ -1,7 +1,8 @@
 """Randomised sweep of the one-pass-per-mode sparse sketch (csrc/sparse_fused.hip) against the generator path of round 2
 (sampler.hip + sparse.hip, itself pinned to the oracle) and, for small cases, the oracle -- a tool, not part of the
 collected suite: `python tests/fuzz_sparse_fused.py SEED SECONDS` on a GPU box.  Random orders 2..6, mode sizes 1..400,
-nonzero counts 1..3e5 (duplicates included), ranks 1..16 with rank slices, table / in-pass factors in every mix."""
+nonzero counts 1..3e5 (duplicates included), ranks 1..32 with rank slices, SparseGaussianDRM / SparseSignDRM in every pairing
+(sign rows with random non-zero counts), table / in-pass factors in every mix."""
 import os
 import sys
 import time
@@ -25,11 +26,26 @@ while time.time() - t0 < budget:
     val = rng.standard_normal(nnz)
     lo_l = tuple(int(rng.integers(0, 3)) for _ in range(d - 1))
     lo_r = tuple(int(rng.integers(0, 3)) for _ in range(d - 1))
-    hi_l = tuple(a + int(rng.integers(1, 17)) for a in lo_l)
-    hi_r = tuple(a + int(rng.integers(1, 17)) for a in lo_r)
+    wmax = 33 if rng.random() < 0.5 else 17
+    hi_l = tuple(a + int(rng.integers(1, wmax)) for a in lo_l)
+    hi_r = tuple(a + int(rng.integers(1, wmax)) for a in lo_r)
     sl, sr = int(rng.integers(0, 2**31)), int(rng.integers(0, 2**31))
-    mk = lambda: (tsa.SparseGaussianDRM(hi_l, shape, False, seed=sl, rank_min=lo_l, rank_max=hi_l, true_rank=hi_l),
-                  tsa.SparseGaussianDRM(hi_r, shape, True, seed=sr, rank_min=lo_r, rank_max=hi_r, true_rank=hi_r))
+    kl, kr = ("s" if rng.random() < 0.4 else "g"), ("s" if rng.random() < 0.4 else "g")
+    tr_l = tuple(h + int(rng.integers(0, 3)) for h in hi_l)          # sign rows longer than the slice used
+    tr_r = tuple(h + int(rng.integers(0, 3)) for h in hi_r)
+    nz_l = tuple(int(rng.integers(0, t + 1)) for t in tr_l)
+    nz_r = tuple(int(rng.integers(0, t + 1)) for t in tr_r)
+
+    def one(kind, transpose, seed, lo, hi, tr, nz):
+        # (constructor arguments in the tensor's mode order; a transposed DRM stores them reversed, the oracle's classes take
+        # them in walking order)
+        w = (lambda v: v[::-1]) if transpose else (lambda v: v)
+        if kind == "g":
+            return (tsa.SparseGaussianDRM(hi, shape, transpose, seed=seed, rank_min=lo, rank_max=hi, true_rank=hi),
+                    orc.HashGaussDrm(seed, shape, transpose, w(lo), w(hi)))
+        return (tsa.SparseSignDRM(tr, shape, transpose, seed=seed, rank_min=lo, rank_max=hi, true_rank=tr, num_non_zero_per_row=w(nz)),
+                orc.HashSignDrm(seed, shape, transpose, w(tr), w(lo), w(hi), w(nz)))
+    mk = lambda: (one(kl, False, sl, lo_l, hi_l, tr_l, nz_l)[0], one(kr, True, sr, lo_r, hi_r, tr_r, nz_r)[0])
     os.environ["TTSK_SPARSE_FUSED"] = "1"
     T = tsa.SparseTensor(shape, idx, val)
     ld, rd = mk()
@@ -41,11 +57,11 @@ while time.time() - t0 < budget:
     cases += 1
     err = max(rel(a, b) for a, b in zip(new.Psi_cores + new.Omega_mats, old.Psi_cores + old.Omega_mats))
     if nnz <= 3000 and int(np.prod(shape, dtype=object)) < 2**31:
-        oP, oO = orc.general_sketch("sparse", (shape, idx, val), orc.HashGaussDrm(ld.seed, shape, False, lo_l, hi_l),
-                                    orc.HashGaussDrm(rd.seed, shape, True, lo_r[::-1], hi_r[::-1]), "streaming")
+        oP, oO = orc.general_sketch("sparse", (shape, idx, val), one(kl, False, sl, lo_l, hi_l, tr_l, nz_l)[1],
+                                    one(kr, True, sr, lo_r, hi_r, tr_r, nz_r)[1], "streaming")
         err = max(err, max(rel(a, b) for a, b in zip(new.Psi_cores + new.Omega_mats, oP + oO)))
         oracle_cases += 1
     worst = max(worst, err)
     if not err <= 1e-10:
-        print("FAIL", dict(shape=shape, nnz=nnz, lo_l=lo_l, hi_l=hi_l, lo_r=lo_r, hi_r=hi_r, sl=sl, sr=sr, err=err), flush=True)
+        print("FAIL", dict(shape=shape, nnz=nnz, kl=kl, kr=kr, lo_l=lo_l, hi_l=hi_l, lo_r=lo_r, hi_r=hi_r, tr_l=tr_l, tr_r=tr_r, nz_l=nz_l, nz_r=nz_r, sl=sl, sr=sr, err=err), flush=True)
 print(f"fuzz_sparse_fused: {cases} cases ({oracle_cases} also against the oracle), worst relative difference {worst:.2e}")
