@@ -37,7 +37,9 @@ SHAPES = [(32, 8, 16, 20, 40), (64, 8, 16, 20, 40), (64, 24, 32, 20, 40), (32, 4
           # first modes that are multiples of 32 only; every pairing of the accumulator shapes
           (64, 24, 32, 21, 42), (32, 4096, 16, 21, 42), (64, 40, 48, 32, 64), (32, 72, 128, 25, 48), (64, 264, 64, 20, 41),
           (32, 16, 16, 32, 40), (64, 16, 32, 24, 39), (96, 40, 32, 7, 22), (96, 24, 16, 30, 57), (160, 64, 64, 21, 64),
-          (64, 8, 16, 20, 49), (32, 8, 16, 1, 1), (64, 2056, 16, 29, 33)]
+          (64, 8, 16, 20, 49), (32, 8, 16, 1, 1), (64, 2056, 16, 29, 33),
+          # one side tiny beside a wide other one (found by tests/fuzz_dense_pass.py: the half a kind owns reached beyond the rank)
+          (256, 152, 80, 2, 51), (128, 8, 32, 3, 61), (64, 16, 16, 30, 2), (64, 24, 32, 1, 64), (128, 16, 16, 32, 1)]
 
 
 @pytest.mark.parametrize("n0,Q,T,ll,r", SHAPES)

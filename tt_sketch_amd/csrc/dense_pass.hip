@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void dense_pass_kernel(DensePass a)
     for (int zs = 0; zs < (ZS > 0 ? ZS : 1); ++zs) zps[zs] = 0.0;
     const int64_t zs_row = (int64_t)a.Q * a.T;
     const uint32_t zoff = (uint32_t)((kq * zs_row + x16) * 8);          // 3 Q T doubles at most: the host checks the range
-    const int z_end = a.split && kind == 0 ? a.z_half : a.ll;          // rows of Z this kind owns: [z_off, z_end)
+    const int z_end = a.split && kind == 0 && a.z_half < a.ll ? a.z_half : a.ll;          // rows of Z this kind owns: [z_off, z_end)
     auto store_z = [&](int it) {
         const int64_t at = uniform_i64(((int64_t)bb * a.zblock + ((int64_t)it * 8 + w) * a.T + t0) * 8);
 #pragma unroll
@@ -459,7 +459,7 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     if (rc != TTSK_OK) { set_error("ttsk_dense_first_pass: launch failed"); return rc; }
     const int64_t elems = (int64_t)NB * sl64 * nt * nbb;
     for (int k = 0; k < kinds; ++k) {
-        const int p_off = k * p_half, pcount = split ? (k == 0 ? p_half : (int)r - p_half) : (int)r;
+        const int p_off = k * p_half, pcount = split ? (k == 0 ? std::min<int>(p_half, (int)r) : (int)r - p_half) : (int)r;
         if (pcount <= 0) continue;
         hipLaunchKernelGGL(dense_pass_reduce, dim3((unsigned)cdiv(elems, 256)), dim3(256), 0, st, slab + (size_t)k * grid1 * NB * sl64, NB, TP, SP, nt,
                            (int)nqc, nbb, (int)T, (int)r, U, p_off, pcount);
