@@ -642,14 +642,12 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
         }
         return TTSK_OK;
     }
-    // The end modes need one chain each -- Psi_0 = X_0 R_0 the right one (this stream), Psi_{d-1} = T_{d-1} the left one (the
-    // helper): queued BEFORE the join, they run while their stream would wait for the other chain (the join costs ~16 us of
-    // cross-queue latency) instead of standing behind the Omega launch at the very end (one C3 tensor: 249 -> 238 us).
+    // Psi_0 = X_0 R_0 needs the right chain only (this stream): queued BEFORE the join, it runs while this stream would wait for the
+    // left chain (the join costs ~16 us of cross-queue latency) instead of standing behind the Omega launch at the very end
+    // (one C3 tensor: 0.254 -> 0.239 ms).  (Psi_{d-1}, a copy of the left chain's last T, stays behind the join: on the helper
+    // stream in front of it, it would lengthen the chain the join waits for.)
     const bool ends_early = !sum && d >= 3;
-    if (ends_early) {
-        CK(psi_omega(0, stream, true, false));
-        CK(psi_omega(d - 1, aux, true, false));
-    }
+    if (ends_early) CK(psi_omega(0, stream, true, false));
     CK(ttsk_stream_wait(stream, aux));
     CK(ttsk_stream_wait(aux, stream));
     // Few tensors of one shape in every mode (one C3 tensor: 4 Psi, 5 Omega of equal shapes): the interior Psi
@@ -690,10 +688,8 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                     o.A[cnt] = Lp(b, mu) + l_lo[mu]; o.B[cnt] = Rp(b, jr) + r_lo[jr]; o.C[cnt] = outb(b) + om_at[mu];
                 }
             CK(gemm_batch(5, cnt, desc2(l, r, 1, sp, 1, 0, lt[1], 0, ldr, 1, r, 1, accumulate), o, aux, st_aux));
-            if (!ends_early) {
-                CK(psi_omega(0, aux, true, false));
-                CK(psi_omega(d - 1, stream, true, false));
-            }
+            if (!ends_early) CK(psi_omega(0, aux, true, false));
+            CK(psi_omega(d - 1, stream, true, false));
         }
     }
     if (!grouped) {
@@ -758,7 +754,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
             }
         }
         for (int mu = 0; mu < d; ++mu) {
-            const bool psi_here = !(psi_batched && mu >= 1 && mu < d - 1) && !(ends_early && (mu == 0 || mu == d - 1));
+            const bool psi_here = !(psi_batched && mu >= 1 && mu < d - 1) && !(ends_early && mu == 0);
             if (!psi_here && (om_batched || mu == d - 1)) continue;
             CK(psi_omega(mu, (mu & 1) ? aux : stream, psi_here, !om_batched));
         }
