@@ -354,8 +354,11 @@ int ttsk_tt_orth_sketch(int d, const int64_t *n, const int64_t *s, const int64_t
                         const double *const *X, const double *const *DL, const double *const *DR,
                         double *const *cores_out, double *const *omega_out, int stream);
 /* the same for `count` tensor trains of ONE signature (n, s) against ONE pair of DRMs -- the streaming setting of
- * sketch.py:292-301, and the many same-shaped re-orthogonalisations of tt_gmres.py:293-299 -- as concurrent chains: tensor b
- * on the library streams (stream + 2 (b mod 4), + 1), forked from and joined back into `stream`.
+ * sketch.py:292-301, and the many same-shaped re-orthogonalisations of tt_gmres.py:293-299.  Up to 16 tensors whose
+ * unfoldings are all at least twice as tall as wide, ranks <= 128: ONE chain of launches, every step (chain products,
+ * pseudo-inverses, Gram / Cholesky / triangular products, sign reconstruction) over all tensors at once, one verdict for the
+ * whole batch.  Otherwise as concurrent chains: tensor b on the library streams (stream + 2 (b mod 4), + 1), forked from and
+ * joined back into `stream`, a verdict per tensor.
  *   X, cores_out     count * d pointers, tensor-major;   omega_out   count * (d - 1) pointers (orthogonal)
  *   dev_status       count ints in device memory: 1 = a fast factorisation of that tensor was rejected (repeat it on the
  *                    robust path: ttsk_pinv / ttsk_qr_thin); read after ttsk_sync(stream) */

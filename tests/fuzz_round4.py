@@ -3,7 +3,7 @@
   * ttsk_chain_step_sum (chain_sum.h): random term counts, slice counts, ranks inside and around its cover, both stride patterns,
     all three T layouts; shapes it declines are skipped;
   * ttsk_dense_left_pass (dense_left_pass.hip) and the long-K rows product behind ttsk_gemm (dense_right_pass.hip);
-  * orthogonal_sketch_batch / hmt_sketch_batch against the single calls (bit for bit) on random signatures."""
+  * orthogonal_sketch_batch against the single calls (to rounding) on random signatures."""
 import os
 import sys
 import time
@@ -53,7 +53,7 @@ while time.time() - t0 < budget:
             got = tsa.orthogonal_sketch_batch(tts, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
             for t, g in zip(tts, got):
                 one = tsa.orthogonal_sketch(t, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
-                assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(one.cores, g.cores))
+                assert all(np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-8 * np.abs(np.asarray(a)).max() for a, b in zip(one.cores, g.cores))
                 assert g.error(t, relative=True) < 1e-6 or s_in > l      # exact recovery where the sketch rank covers the TT rank
             count["orth_batch"] += 1
     except ValueError:

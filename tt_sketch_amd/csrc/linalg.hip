@@ -1352,6 +1352,91 @@ int qr_signs(const double *Qtop, int n, int square, const double *Sprev, int row
     return 1;
 }
 
+// ---- the same steps for `count` matrices of ONE shape per launch (the tensors of an orthogonalising batch, tt_orth.hip)
+struct QrSignsBatch {
+    const double *Q[16], *Sprev[16];
+    double *Sout[16];
+};
+__global__ __launch_bounds__(1024) void qr_signs_batch_kernel(QrSignsBatch a, int n, int square, int rows_per)
+{
+    extern __shared__ double sm[];
+    const int ld = n + 1, tid = threadIdx.x;
+    double *B = sm, *S = sm + n * ld;
+    __shared__ double shadow[2 * 128];
+    const int nthr = blockDim.x;
+    const double *Qtop = a.Q[blockIdx.x], *Sprev = a.Sprev[blockIdx.x];
+    double *Sout = a.Sout[blockIdx.x];
+    for (int e = tid; e < n * n; e += nthr) {
+        const int r = e / n;
+        B[r * ld + e % n] = Qtop[e] * (Sprev ? Sprev[r / rows_per] : 1.0);
+    }
+    __syncthreads();
+    hh_signs_lds(B, n, ld, square, S, shadow, tid, nthr);
+    for (int c = tid; c < n; c += nthr) Sout[c] = S[c];
+}
+
+// 1 = queued, 0 = outside this path (n beyond one workgroup's LDS, more than 16 matrices)
+int qr_signs_batch(int count, const double *const *Qtop, int n, int square, const double *const *Sprev, int rows_per, double *const *Sout,
+                   hipStream_t st)
+{
+    if (n > CHOL_ONE || count < 1 || count > 16) return 0;
+    static PerInit attr;
+    if (attr.first()) {
+        TTSK_HIP(hipFuncSetAttribute((const void *)qr_signs_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    }
+    QrSignsBatch a{};
+    for (int b = 0; b < count; ++b) { a.Q[b] = Qtop[b]; a.Sprev[b] = Sprev ? Sprev[b] : nullptr; a.Sout[b] = Sout[b]; }
+    hipLaunchKernelGGL(qr_signs_batch_kernel, dim3((unsigned)count), dim3(chol_threads(n)), (size_t)(n * (n + 1) + n) * 8, st, a, n, square, rows_per);
+    TTSK_LAUNCH_CHECK();
+    return 1;
+}
+
+size_t qr_batch_ws_elems(int count, int64_t m, int n) { return (size_t)count * ((size_t)m * n + 3 * (size_t)n * n) + (size_t)count + 16; }
+
+// CholeskyQR2 of `count` tall matrices of one shape (m x n row-major, in place), UNSIGNED factors (R's diagonal positive: the caller
+// reconstructs Householder's signs, qr_signs_batch): two Gram products, two factorisations, two triangular products, each ONE
+// launch over all matrices (tensor by tensor where a shape has no batched kernel).  Verdicts into *sticky (deferred).
+// 1 = queued, 0 = outside this path -- nothing has been queued then.
+int qr_cholesky_batch(int count, double *const *A, int64_t m, int n, int stream, hipStream_t st, double *ws, int *sticky)
+{
+    if (count < 1 || count > 16 || n > CHOL_ONE || m < 2 * (int64_t)n || !ws || !sticky) return 0;
+    double *Q1 = ws, *G = Q1 + (size_t)count * m * n, *R1 = G + (size_t)count * n * n, *R2 = R1 + (size_t)count * n * n;
+    int *status = (int *)(R2 + (size_t)count * n * n);
+    const double *cA[16], *cQ1[16], *cR1[16], *cR2[16];
+    double *pQ1[16], *pG[16];
+    for (int b = 0; b < count; ++b) {
+        cA[b] = A[b]; pQ1[b] = Q1 + (size_t)b * m * n; cQ1[b] = pQ1[b];
+        pG[b] = G + (size_t)b * n * n; cR1[b] = R1 + (size_t)b * n * n; cR2[b] = R2 + (size_t)b * n * n;
+    }
+    auto desc = [](int64_t M, int64_t N, int64_t K, int64_t a_m, int64_t a_k, int64_t b_k, int64_t b_n) {
+        ttsk_gemm_desc d{};
+        d.batch = 1; d.M = M; d.N = N; d.Ko = 1; d.Ki = K;
+        d.a_m = a_m; d.a_ki = a_k; d.b_ki = b_k; d.b_n = b_n; d.c_m = N; d.c_n = 1; d.alpha = 1.0;
+        return d;
+    };
+    const ttsk_gemm_desc gram = desc(n, n, m, 1, n, n, 1), tri = desc(m, n, n, n, 1, n, 1);
+    // one product for every matrix: a batched launch where the shape has one (tall: skinny.h; small: small.hip), else one by one
+    auto prod = [&](const ttsk_gemm_desc &g, const double *const *X, const double *const *Y, double *const *Z) -> int {
+        int r = skinny_try_batch(g, count, X, Y, Z, stream, st);
+        if (r == 0) r = small_try_batch(g, count, X, Y, Z, stream, st);
+        if (r != 0) return r < 0 ? r : TTSK_OK;
+        for (int b = 0; b < count; ++b)
+            if ((r = small_gemm(g.M, g.N, g.Ki, X[b], g.a_m, g.a_ki, Y[b], g.b_ki, g.b_n, Z[b], stream))) return r;
+        return TTSK_OK;
+    };
+    int rc;
+    if ((rc = prod(gram, cA, cA, pG))) return rc;                                                             // A^T A
+    if ((rc = launch_chol(G, n, R1, nullptr, status, 1e-6, st, sticky, nullptr, count))) return rc;           // kappa(A) up to ~1e6
+    if ((rc = prod(tri, cA, cR1, pQ1))) return rc;                                                            // Q1 = A R1^-1
+    if ((rc = prod(gram, cQ1, cQ1, pG))) return rc;                                                           // Q1^T Q1 ~ identity
+    static const int chol_expand = [] { const char *e = getenv("TTSK_CHOL_EXPAND"); return e ? atoi(e) : 1; }();
+    hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)count), dim3(256), (size_t)(n * (n + 1) + n) * 8, st, (const double *)G, n, R2, (double *)nullptr,
+                       status + count, 0.5, sticky, (double *)nullptr, (const double *)nullptr, 0, chol_expand ? 2 : 0);
+    TTSK_LAUNCH_CHECK();
+    if ((rc = prod(tri, cQ1, cR2, A))) return rc;                                                             // Q = Q1 R2^-1
+    return 1;
+}
+
 // core[a, i, b] *= sp[a] sn[b] for up to 16 cores in one launch (sp / sn may be nullptr = all ones)
 struct SignFix { double *core[16]; const double *sp[16], *sn[16]; int k0[16], nn[16], k1[16]; };
 __global__ __launch_bounds__(256) void apply_signs_kernel(SignFix f)

@@ -25,4 +25,9 @@ int pinv_deferred(const double *omega, int64_t l, int64_t r, double *pinv, int s
 int apply_signs(int count, double *const *cores, const double *const *sp, const double *const *sn, const int *k0, const int *nn,
                 const int *k1, hipStream_t st);
 constexpr int QR_CHOL_MAX_N = 256;       // largest column count of qr_cholesky
+// the same steps for `count` <= 16 matrices of one shape per launch; 1 = queued, 0 = outside this path (then nothing was written)
+size_t qr_batch_ws_elems(int count, int64_t m, int n);
+int qr_cholesky_batch(int count, double *const *A, int64_t m, int n, int stream, hipStream_t st, double *ws, int *sticky);
+int qr_signs_batch(int count, const double *const *Qtop, int n, int square, const double *const *Sprev, int rows_per, double *const *Sout,
+                   hipStream_t st);
 }  // namespace ttsk

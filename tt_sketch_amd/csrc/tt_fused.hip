@@ -242,7 +242,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     TTSK_ARG(d >= 2, "ttsk_tt_sketch: need d >= 2, got %d", d);
     TTSK_ARG(n && s && lt && l_lo && l_hi && rt && r_lo && r_hi && X && DR && (co ? (DL || !co->want_left) : (DL && out)),
              "ttsk_tt_sketch: NULL argument");
-    TTSK_ARG(!co || (nb == 1 && !sum && !accumulate), "ttsk_tt_sketch: chains-only mode is for one tensor");
+    TTSK_ARG(!co || (nb <= SK_MAXB && !sum && !accumulate), "ttsk_tt_sketch: chains-only mode takes one slice of tensors");
     const bool no_left = co && !co->want_left;
     TTSK_ARG(s[0] == 1 && s[d] == 1 && lt[0] == 1 && rt[0] == 1, "ttsk_tt_sketch: boundary ranks must be 1");
     for (int mu = 0; mu < d - 1; ++mu) {
@@ -252,7 +252,7 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
                  "ttsk_tt_sketch: right rank slice %d out of range", mu);
     }
     const int64_t one = ttsk_tt_sketch_size(d, n, l_lo, l_hi, r_lo, r_hi);
-    TTSK_ARG(sum || nb == 1 || out_stride >= one, "ttsk_tt_sketch_batch: out_stride %lld < sketch size %lld",
+    TTSK_ARG(co || sum || nb == 1 || out_stride >= one, "ttsk_tt_sketch_batch: out_stride %lld < sketch size %lld",
              (long long)out_stride, (long long)one);
     if (nb > SK_MAXB) {   // larger batches in slices of SK_MAXB tensors
         for (int b0 = 0; b0 < nb; b0 += SK_MAXB) {
@@ -620,25 +620,33 @@ static int tt_sketch_core(int nb, int d, const int64_t *n, const int64_t *s, con
     }
     // both chains are needed from here on, on both streams
     if (co) {
-        for (int j = 0; j < d - 1; ++j) co->Rc[j] = Rp(0, j);
-        for (int mu = 0; mu < d - 1; ++mu) co->Lc[mu] = no_left ? nullptr : Lp(0, mu);
+        for (int j = 0; j < d - 1; ++j) { co->Rc[j] = Rp(0, j); co->r_stride[j] = (int64_t)szR[j]; }
+        for (int mu = 0; mu < d - 1; ++mu) { co->Lc[mu] = no_left ? nullptr : Lp(0, mu); co->l_stride[mu] = (int64_t)szL[mu]; }
         if (no_left) return TTSK_OK;
         CK(ttsk_stream_wait(stream, aux));   // join
-        // Omega_mu = L_mu^T R_mu: one batched launch when the modes share a shape
+        // Omega_mu = L_mu^T R_mu: batched launches over (tensor, mode) when the modes share a shape
         bool same = true;
         for (int mu = 1; mu < d - 1; ++mu)
             same = same && s[mu + 1] == s[1] && lt[mu + 1] == lt[1] && rt[d - 1 - mu] == rt[d - 1];
-        BatchPtrs o{};
-        for (int mu = 0; mu < d - 1; ++mu) { o.A[mu] = Lp(0, mu); o.B[mu] = Rp(0, d - 2 - mu); o.C[mu] = co->omega[mu]; }
-        if (same && d - 1 <= SK_MAXB) {
-            CK(gemm_batch(5, d - 1, desc2(lt[1], rt[d - 1], 1, s[1], 1, 0, lt[1], 0, rt[d - 1], 1, rt[d - 1], 1, 0), o, stream, st));
+        if (same) {
+            BatchPtrs o{};
+            int cnt = 0;
+            for (int b = 0; b < nb; ++b)
+                for (int mu = 0; mu < d - 1; ++mu) {
+                    o.A[cnt] = Lp(b, mu); o.B[cnt] = Rp(b, d - 2 - mu); o.C[cnt] = co->omega[(size_t)b * (d - 1) + mu];
+                    if (++cnt == SK_MAXB || (b == nb - 1 && mu == d - 2)) {
+                        CK(gemm_batch(5, cnt, desc2(lt[1], rt[d - 1], 1, s[1], 1, 0, lt[1], 0, rt[d - 1], 1, rt[d - 1], 1, 0), o, stream, st));
+                        cnt = 0;
+                    }
+                }
         } else {
-            for (int mu = 0; mu < d - 1; ++mu) {
-                BatchPtrs o1{};
-                o1.A[0] = o.A[mu]; o1.B[0] = o.B[mu]; o1.C[0] = o.C[mu];
-                const int64_t l = lt[mu + 1], r = rt[d - 1 - mu];
-                CK(gemm_batch(5, 1, desc2(l, r, 1, s[mu + 1], 1, 0, l, 0, r, 1, r, 1, 0), o1, stream, st));
-            }
+            for (int b = 0; b < nb; ++b)
+                for (int mu = 0; mu < d - 1; ++mu) {
+                    BatchPtrs o1{};
+                    o1.A[0] = Lp(b, mu); o1.B[0] = Rp(b, d - 2 - mu); o1.C[0] = co->omega[(size_t)b * (d - 1) + mu];
+                    const int64_t l = lt[mu + 1], r = rt[d - 1 - mu];
+                    CK(gemm_batch(5, 1, desc2(l, r, 1, s[mu + 1], 1, 0, l, 0, r, 1, r, 1, 0), o1, stream, st));
+                }
         }
         return TTSK_OK;
     }
@@ -771,13 +779,20 @@ namespace ttsk {
 int tt_chains(int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt, const double *const *X,
               const double *const *DL, const double *const *DR, TTChains *out, int stream)
 {
+    return tt_chains_batch(1, d, n, s, lt, rt, X, DL, DR, out, stream);
+}
+
+int tt_chains_batch(int nb, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt, const double *const *X,
+                    const double *const *DL, const double *const *DR, TTChains *out, int stream)
+{
     if (d < 2 || d > 64 || !out) { set_error("tt_chains: bad argument"); return TTSK_ERR_ARG; }
     std::vector<int64_t> zero(d, 0), lhi(d, 1), rhi(d, 1), ones(d + 1, 1);
     for (int mu = 0; mu < d - 1; ++mu) {
         if (out->want_left) lhi[mu] = lt[mu + 1];
         rhi[mu] = rt[mu + 1];
     }
-    return tt_sketch_core(1, d, n, s, out->want_left ? lt : ones.data(), zero.data(), lhi.data(), rt, zero.data(), rhi.data(), X,
+    if (nb < 1 || nb > SK_MAXB) { set_error("tt_chains: %d tensors (1 .. %d)", nb, SK_MAXB); return TTSK_ERR_ARG; }
+    return tt_sketch_core(nb, d, n, s, out->want_left ? lt : ones.data(), zero.data(), lhi.data(), rt, zero.data(), rhi.data(), X,
                           DL, DR, nullptr, 0, 0, stream, false, out);
 }
 

@@ -203,6 +203,188 @@ __global__ void orth_take_flag_kernel(int *sticky, int *dst)
     if (threadIdx.x == 0) { *dst = *sticky; *sticky = 0; }
 }
 
+// verdict of a fused batch: one flag for all its tensors
+__global__ void orth_spread_flag_kernel(int *sticky, int *dst, int count)
+{
+    if (threadIdx.x == 0) {
+        const int v = *sticky;
+        *sticky = 0;
+        for (int b = 0; b < count; ++b) dst[b] = v;
+    }
+}
+
+// The batch as ONE chain of launches: every step of ttsk_tt_orth_sketch over all `count` tensors at once -- the DRM chains and Omega
+// (tt_chains_batch), the pseudo-inverses and W = R Omega^+ (batched over (tensor, mode)), then per mode T, M = T W, CholeskyQR2
+// (qr_cholesky_batch), the sign reconstruction (qr_signs_batch, helper stream) and the next chain matrix, each one launch with
+// `count` problems.  ~90 launches per batch instead of per tensor, on operands count times larger.  The fast factorisations'
+// verdict is one flag for the whole batch (a rejection repeats every tensor of it on its own).
+// 1 = done, 0 = shapes outside this path (nothing written that the caller may not overwrite), < 0 = error.
+static int orth_batch_fused(int count, int d, const int64_t *n, const int64_t *s, const int64_t *lt, const int64_t *rt,
+                            const double *const *X, const double *const *DL, const double *const *DR, double *const *cores_out,
+                            double *const *omega_out, int *dev_status, int stream)
+{
+    TTSK_STREAM(st, stream);
+    const bool orth = DL != nullptr;
+    static const int on = [] { const char *e = getenv("TTSK_ORTH_BATCH_FUSED"); return e ? atoi(e) : 1; }();
+    if (!on || count < 2 || count > 16 || d < 2 || d - 1 > SK_MAXB || !fast_solves()) return 0;
+    int *sticky = deferred_flag(stream);
+    if (!sticky) return 0;
+    auto rr = [&](int mu) { return rt[d - 1 - mu]; };
+    auto kk = [&](int mu) { return mu < 0 ? (int64_t)1 : (orth ? lt[mu + 1] : rr(mu)); };
+    int64_t mmax = 0, kmax = 0, smax = 0, tmax = 0, lmax = 1;
+    size_t pmax = 0;
+    for (int mu = 0; mu < d; ++mu) {
+        const int64_t m = kk(mu - 1) * n[mu];
+        tmax = std::max(tmax, m * s[mu + 1]);
+        smax = std::max(smax, s[mu + 1]);
+        if (mu == d - 1) break;
+        // every unfolding at least twice as tall as wide (CholeskyQR2 + signs beside the chain), factors within one workgroup's LDS
+        if (kk(mu) > 128 || m < 2 * kk(mu)) return 0;
+        if (orth && (std::min(lt[mu + 1], rr(mu)) > 128 || lt[mu + 1] != lt[1] || rr(mu) != rr(0) || s[mu + 1] != s[1])) return 0;
+        mmax = std::max(mmax, m);
+        kmax = std::max(kmax, kk(mu));
+        if (orth) { pmax = std::max(pmax, (size_t)rr(mu) * lt[mu + 1]); lmax = std::max(lmax, lt[mu + 1]); }
+    }
+    int rc;
+#define CK(x) do { rc = (x); if (rc < 0) return rc; } while (0)
+    // ---- 1. chains (and Omega) of all tensors
+    TTChains ch{};
+    ch.want_left = orth ? 1 : 0;
+    ch.omega = omega_out;
+    CK(tt_chains_batch(count, d, n, s, lt, rt, X, DL, DR, &ch, stream));
+    auto Rc = [&](int b, int j) { return ch.Rc[j] + (size_t)b * ch.r_stride[j]; };
+    // ---- workspace
+    auto blk = [](size_t v) { return (v + 31) & ~(size_t)31; };
+    const size_t szP = orth ? blk(pmax) : 0, szW = orth ? blk((size_t)smax * lmax) : 0;
+    const size_t szL = blk((size_t)smax * kmax), szT = blk((size_t)tmax), szS = blk((size_t)kmax);
+    const size_t szQ = blk(qr_batch_ws_elems(count, mmax, (int)kmax));
+    const size_t per_t = (size_t)(d - 1) * (szP + szW + szS) + 2 * szL + szT;
+    double *ws = (double *)scratch(stream, SCRATCH_ORTH, ((size_t)count * per_t + szQ) * 8);
+    if (!ws) return TTSK_ERR_HIP;
+    double *P0 = ws, *W0 = P0 + (size_t)count * (d - 1) * szP, *Sb = W0 + (size_t)count * (d - 1) * szW;
+    double *Lb = Sb + (size_t)count * (d - 1) * szS, *Tb = Lb + (size_t)count * 2 * szL, *qws = Tb + (size_t)count * szT;
+    auto Pv = [&](int b, int mu) { return P0 + ((size_t)b * (d - 1) + mu) * szP; };
+    auto Wv = [&](int b, int mu) { return W0 + ((size_t)b * (d - 1) + mu) * szW; };
+    auto Sv = [&](int b, int mu) { return Sb + ((size_t)b * (d - 1) + mu) * szS; };
+    auto desc = [](int64_t M, int64_t N, int64_t K, int64_t a_m, int64_t a_k, int64_t b_k, int64_t b_n) {
+        ttsk_gemm_desc g{};
+        g.batch = 1; g.M = M; g.N = N; g.Ko = 1; g.Ki = K;
+        g.a_m = a_m; g.a_ki = a_k; g.b_ki = b_k; g.b_n = b_n; g.c_m = N; g.c_n = 1; g.alpha = 1.0;
+        return g;
+    };
+    // one product for every tensor: a batched launch where the shape has one, tensor by tensor otherwise
+    auto prod = [&](const ttsk_gemm_desc &g, const double *const *A, const double *const *B, double *const *C) -> int {
+        int r = skinny_try_batch(g, count, A, B, C, stream, st);
+        if (r == 0) r = small_try_batch(g, count, A, B, C, stream, st);
+        if (r != 0) return r < 0 ? r : TTSK_OK;
+        for (int b = 0; b < count; ++b) {
+            r = gemm2(g.M, g.N, g.Ki, A[b], g.a_m, g.a_ki, B[b], g.b_ki, g.b_n, C[b], stream);
+            if (r < 0) return r;
+        }
+        return TTSK_OK;
+    };
+    // ---- 2. W_b,mu = R_b,mu Omega_b,mu^+
+    std::vector<const double *> W((size_t)count * (d - 1));
+    if (orth) {
+        const double *om[SK_MAXB], *A[SK_MAXB], *B[SK_MAXB];
+        double *pv[SK_MAXB], *C[SK_MAXB];
+        int cnt = 0;
+        for (int b = 0; b < count; ++b)
+            for (int mu = 0; mu < d - 1; ++mu) {
+                om[cnt] = omega_out[(size_t)b * (d - 1) + mu]; pv[cnt] = Pv(b, mu);
+                A[cnt] = Rc(b, d - 2 - mu); B[cnt] = pv[cnt]; C[cnt] = Wv(b, mu);
+                W[(size_t)b * (d - 1) + mu] = C[cnt];
+                if (++cnt == SK_MAXB || (b == count - 1 && mu == d - 2)) {
+                    CK(ttsk_pinv_batch_deferred(cnt, om, lt[1], rr(0), pv, stream));
+                    ttsk_gemm_desc g = desc(s[1], lt[1], rr(0), rr(0), 1, lt[1], 1);
+                    int done = small_try_batch(g, cnt, A, B, C, stream, st);
+                    if (done < 0) return done;
+                    if (!done)
+                        for (int q = 0; q < cnt; ++q) CK(gemm2(s[1], lt[1], rr(0), A[q], rr(0), 1, B[q], lt[1], 1, C[q], stream));
+                    cnt = 0;
+                }
+            }
+    } else {
+        for (int b = 0; b < count; ++b)
+            for (int mu = 0; mu < d - 1; ++mu) W[(size_t)b * (d - 1) + mu] = Rc(b, d - 2 - mu);
+    }
+    // ---- 3. the modes, every step over all tensors (signs beside the chain as in the single call)
+    const int aux = (stream + 1) % TTSK_NUM_STREAMS;
+    TTSK_STREAM(st_aux, aux);
+    std::vector<const double *> Sg((size_t)count * d, nullptr);
+    auto fix_cores = [&](int mu) -> int {
+        double *c[16];
+        const double *spv[16], *snv[16];
+        int k0[16], nv[16], k1[16];
+        bool any = false;
+        for (int b = 0; b < count; ++b) {
+            spv[b] = mu > 0 ? Sg[(size_t)b * d + mu - 1] : nullptr;
+            snv[b] = mu < d - 1 ? Sg[(size_t)b * d + mu] : nullptr;
+            any = any || spv[b] || snv[b];
+            c[b] = cores_out[(size_t)b * d + mu];
+            k0[b] = (int)kk(mu - 1); nv[b] = (int)n[mu]; k1[b] = mu < d - 1 ? (int)kk(mu) : 1;
+        }
+        if (!any) return TTSK_OK;
+        int r = ttsk_stream_wait(aux, stream);
+        if (r < 0) return r;
+        return apply_signs(count, c, spv, snv, k0, nv, k1, st_aux);
+    };
+    const double *Tm[16], *Lc[16], *Xm[16], *Wm[16];
+    double *Ln[16], *Q[16], *Td[16];
+    int flip = 0;
+    for (int mu = 0; mu < d; ++mu) {
+        const int64_t kp = kk(mu - 1), nn = n[mu], sn = s[mu], sp = s[mu + 1], m = kp * nn;
+        for (int b = 0; b < count; ++b) {
+            Xm[b] = X[(size_t)b * d + mu];
+            Lc[b] = Lb + ((size_t)b * 2 + flip) * szL;
+            Ln[b] = Lb + ((size_t)b * 2 + (flip ^ 1)) * szL;
+        }
+        if (mu == 0) {
+            for (int b = 0; b < count; ++b) Tm[b] = Xm[b];
+        } else {
+            for (int b = 0; b < count; ++b) { Td[b] = mu == d - 1 ? cores_out[(size_t)b * d + mu] : Tb + (size_t)b * szT; Tm[b] = Td[b]; }
+            CK(prod(desc(kp, nn * sp, sn, 1, kp, nn * sp, 1), Lc, Xm, Td));                 // T[q, i, p'] = sum_p Lc[p, q] X[p, i, p']
+        }
+        if (mu == d - 1) {
+            if (mu == 0)
+                for (int b = 0; b < count; ++b)
+                    TTSK_HIP(hipMemcpyAsync(cores_out[(size_t)b * d], Xm[b], (size_t)nn * 8, hipMemcpyDeviceToDevice, st));
+            break;
+        }
+        const int64_t k = kk(mu);
+        for (int b = 0; b < count; ++b) { Q[b] = cores_out[(size_t)b * d + mu]; Wm[b] = W[(size_t)b * (d - 1) + mu]; }
+        CK(prod(desc(m, k, sp, sp, 1, k, 1), Tm, Wm, Q));                                     // M = T W
+        rc = qr_cholesky_batch(count, Q, m, (int)k, stream, st, qws, sticky);
+        if (rc < 0) return rc;
+        if (rc == 0) { set_error("ttsk_tt_orth_sketch_batch: batched QR outside its cover at mode %d", mu); return TTSK_ERR_UNSUPPORTED; }
+        {
+            const double *cq[16], *sprev[16];
+            double *sout[16];
+            for (int b = 0; b < count; ++b) {
+                cq[b] = Q[b]; sprev[b] = mu > 0 ? Sg[(size_t)b * d + mu - 1] : nullptr; sout[b] = Sv(b, mu);
+                Sg[(size_t)b * d + mu] = sout[b];
+            }
+            CK(ttsk_stream_wait(aux, stream));                                               // the unsigned factors are there
+            rc = qr_signs_batch(count, cq, (int)k, m == k ? 1 : 0, mu > 0 ? sprev : nullptr, (int)nn, sout, st_aux);
+            if (rc < 0) return rc;
+            if (rc == 0) { set_error("ttsk_tt_orth_sketch_batch: batched sign reconstruction outside its cover"); return TTSK_ERR_UNSUPPORTED; }
+        }
+        {
+            const double *cq[16];
+            for (int b = 0; b < count; ++b) cq[b] = Q[b];
+            CK(prod(desc(sp, k, m, 1, sp, k, 1), Tm, cq, Ln));                                // next chain matrix Ln = T^T Q
+        }
+        flip ^= 1;
+        CK(fix_cores(mu));                                                                     // the chain has read Q for the last time
+    }
+    CK(fix_cores(d - 1));
+    CK(ttsk_stream_wait(stream, aux));
+    hipLaunchKernelGGL(orth_spread_flag_kernel, dim3(1), dim3(64), 0, st, sticky, dev_status, count);
+    TTSK_LAUNCH_CHECK();
+#undef CK
+    return 1;
+}
+
 // `count` tensor trains of ONE signature against ONE pair of DRMs (sketch.py:292-301: further tensors are sketched with the
 // DRMs of the first): the sketches are independent chains of ~90 short, dependent launches each -- latency, not throughput
 // (0.07 of the matrix peak per call at C3) -- so tensor b runs on the stream pair (2 b mod 8, + 1) beside three others; the
@@ -216,7 +398,10 @@ int ttsk_tt_orth_sketch_batch(int count, int d, const int64_t *n, const int64_t 
     (void)st;
     TTSK_ARG(count >= 1 && X && cores_out && dev_status, "ttsk_tt_orth_sketch_batch: bad argument");
     TTSK_ARG(!DL || omega_out, "ttsk_tt_orth_sketch_batch: the orthogonal method needs omega_out");
-    int rc;
+    int rc = orth_batch_fused(count, d, n, s, lt, rt, X, DL, DR, cores_out, omega_out, dev_status, stream);
+    if (rc == 1) return TTSK_OK;
+    if (rc < 0 && rc != TTSK_ERR_UNSUPPORTED) return rc;
+    // (outside the fused batch's cover: the tensors as concurrent chains, below)
     bool used[TTSK_NUM_STREAMS] = {};
     const int lanes = TTSK_NUM_STREAMS / 2;
     auto pair_of = [&](int b) { return (stream + 2 * (b % lanes)) % TTSK_NUM_STREAMS; };
