@@ -739,7 +739,7 @@ def bench_c2(args, job, gaussian=False):
         cover = [dict(drm="TensorTrainDRM l=20 r=40 (in cover)", ms=1e3 * t_step)]
         for lw, rw in ((21, 42), (20, 41), (32, 64)):
             lw_drm, rw_drm = tsa.TensorTrainDRM(lw, shape, False, seed=1), tsa.TensorTrainDRM(rw, shape, True, seed=2)
-            _, med = timed_calls(nat, lambda: tsa.general_sketch(T, lw_drm, rw_drm, tsa.SketchMethod.streaming), reps=3)
+            _, med = timed_calls(nat, lambda: tsa.general_sketch(T, lw_drm, rw_drm, tsa.SketchMethod.streaming), reps=7, warm=3)
             cover.append(dict(drm=f"TensorTrainDRM l={lw} r={rw}", ms=med, vs_in_cover=med / (1e3 * t_step)))
     base = dict(metric=metric_name(), value=5 / t_step, unit="TT-cores/s", n_gpus=args.gpus, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * t_step, higher_is_better=True, scaling="weak", vs_baseline=None,
