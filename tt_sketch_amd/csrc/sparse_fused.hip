@@ -77,9 +77,21 @@ __host__ __device__ inline size_t sg_per_wave(int tcols, int tab, int qcols)
 
 // NT: 16-column matrix tiles per factor.  NT = 1 (every factor <= 16 columns: C4) is the round-3 kernel; NT = 2 takes
 // factors of up to 32 columns with 2 x 2 accumulator tiles per product (two waves per SIMD: 64 accumulator registers).
-template <int NT>
+__device__ __forceinline__ double sg_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// accumulators of one product when the factors reach NS 4-wide strips beyond their first 16 columns (NS = 1: <= 20 columns, 2: <= 24):
+// the 16 x 16 tile, NS column strips (rows 0..15 x columns 16 + 4 q ..: A as for the tile, B replicated over the four blocks of
+// v_mfma_f64_4x4x4), NS row strips (rows 16 + 4 q .. x columns 0..15: A replicated, B as for the tile) and the corner as the same
+// row strips against B's second 16 columns.  64 + 3 NS x 16 matrix cycles per four nonzeros instead of the 256 of 2 x 2 tiles
+// (fp64 matrix instructions run on the vector ALU's FMA units: padding is paid for).
+template <int NS> struct SgEdge { v4d t; double sb[NS], sa[NS], c[NS]; };
+template <int NS> struct SgOps { double t, s[NS], b1; };
+
+template <int NT, int NS>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 {
+    static_assert(NS == 0 || NT == 2, "edge strips belong to the wide instantiation");
+    constexpr int NSA = NS ? NS : 1;
     extern __shared__ double sg_lds[];
     __shared__ uint64_t salt[3][16 * NT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -123,6 +135,29 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             accP[i][k] = v4d{0.0, 0.0, 0.0, 0.0};
             accO[i][k] = v4d{0.0, 0.0, 0.0, 0.0};
         }
+    SgEdge<NSA> eP, eO;
+    auto edge_zero = [](SgEdge<NSA> &P) {
+        P.t = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NSA; ++q) { P.sb[q] = 0.0; P.sa[q] = 0.0; P.c[q] = 0.0; }
+    };
+    edge_zero(eP);
+    edge_zero(eO);
+    // the cells of an edge set to dst[row * stride + col] where row < wa and col < wb
+    auto edge_store = [&](const SgEdge<NSA> &P, double *dst, int64_t stride, int wa, int wb) {
+        const int beta = x16 >> 2, j4 = x16 & 3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int aa = 4 * t + kq;
+            if (aa < wa && x16 < wb) dst[aa * stride + x16] = P.t[t];
+        }
+#pragma unroll
+        for (int q = 0; q < NSA; ++q) {
+            { const int aa = 4 * beta + kq, cc = 16 + 4 * q + j4; if (aa < wa && cc < wb) dst[aa * stride + cc] = P.sb[q]; }
+            { const int aa = 16 + 4 * q + kq; if (aa < wa && x16 < wb) dst[aa * stride + x16] = P.sa[q]; }
+            { const int aa = 16 + 4 * q + kq, cc = 16 + x16; if (aa < wa && cc < wb) dst[aa * stride + cc] = P.c[q]; }
+        }
+    };
     int cur = jfirst;
     bool first_done = false;
 
@@ -141,6 +176,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
         } else {
             dst = a.psi + (size_t)k * wB;
             stride_a = (int64_t)a.n * wB;
+        }
+        if constexpr (NS > 0) {
+            edge_store(eP, dst, stride_a, wA, wB);
+            edge_zero(eP);
+            return;
         }
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta)
@@ -298,7 +338,83 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
                 cv[t] = lc;
             }
         };
-        if (tile_one_slice) {
+        if constexpr (NS > 0) {
+            // ---- factors of 17 .. 16 + 4 NS columns: tile + edge strips.  Per factor and k-block: the tile operand (column x16), NS
+            // strip operands (column 16 + 4 q + (x16 & 3)) and the second-tile operand (column 16 + x16); whatever lies beyond a
+            // factor's width is garbage that only reaches cells never stored.
+            const double one16 = x16 == 0 ? 1.0 : 0.0;
+            const int j4 = x16 & 3;
+            const double *q0 = p0 - x16, *q1 = p1 - x16, *q2 = p2 - x16;
+            const bool one0 = a.f[0].kind == 0, one1 = a.f[1].kind == 0;
+            auto ld = [&](const double *qf, int se, bool one, int b) {
+                const double *r = qf + 4 * b * se;
+                SgOps<NSA> o;
+                o.t = one ? one16 : r[x16];
+                o.b1 = one ? 0.0 : r[16 + x16];
+#pragma unroll
+                for (int q = 0; q < NSA; ++q) o.s[q] = one ? 0.0 : r[16 + 4 * q + j4];
+                return o;
+            };
+            auto scaled = [&](SgOps<NSA> o, double v) {
+                o.t *= v;
+#pragma unroll
+                for (int q = 0; q < NSA; ++q) o.s[q] *= v;
+                return o;
+            };
+            auto mac = [&](SgEdge<NSA> &P, const SgOps<NSA> &A, const SgOps<NSA> &B) {
+                P.t = mfma16(A.t, B.t, P.t);
+#pragma unroll
+                for (int q = 0; q < NSA; ++q) P.sb[q] = sg_mfma4(A.t, B.s[q], P.sb[q]);
+#pragma unroll
+                for (int q = 0; q < NSA; ++q) P.sa[q] = sg_mfma4(A.s[q], B.t, P.sa[q]);
+#pragma unroll
+                for (int q = 0; q < NSA; ++q) P.c[q] = sg_mfma4(A.s[q], B.b1, P.c[q]);
+            };
+            auto kblock = [&](int b, double v, double vpsi, auto with_om, auto cleft) {
+                const SgOps<NSA> f0 = ld(q0, se0, one0, b), f1 = ld(q1, se1, one1, b);
+                if constexpr (decltype(with_om)::value) {
+                    const SgOps<NSA> f2 = ld(q2, se2, false, b);
+                    if constexpr (decltype(cleft)::value) mac(eO, scaled(f2, v), f1);
+                    else mac(eO, scaled(f0, v), f2);
+                }
+                mac(eP, scaled(f0, vpsi), f1);
+            };
+            auto run = [&](auto with_om, auto cleft) {
+                if (tile_one_slice) {
+#pragma unroll 2
+                    for (int b = 0; b < SG_T / 4; ++b) {
+                        const double v = rv[4 * b + kq];
+                        kblock(b, v, v, with_om, cleft);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int b = 0; b < SG_T / 4; ++b) {
+                        const int e = 4 * b + kq;
+                        const int je = rj[e];
+                        const bool ok = je >= 0;
+                        const double v = rv[e];
+                        if (__ballot(ok && je != cur) == 0ull) {
+                            kblock(b, v, v, with_om, cleft);
+                        } else {
+                            kblock(b, v, 0.0, with_om, cleft);            // Omega of the k-block (and nothing into Psi), then Psi nonzero by nonzero
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const int okq = __shfl((int)ok, 16 * qq);
+                                const int jq = __shfl(je, 16 * qq);
+                                if (!okq) continue;
+                                if (jq != cur) {
+                                    flush(cur, false);
+                                    cur = jq;
+                                }
+                                kblock(b, 0.0, kq == qq ? v : 0.0, std::false_type{}, cleft);
+                            }
+                        }
+                    }
+                }
+            };
+            if (!a.has_om) run(std::false_type{}, std::false_type{});
+            else if (a.c_left) run(std::true_type{}, std::true_type{});
+            else run(std::true_type{}, std::false_type{});
+        } else if (tile_one_slice) {
             // every nonzero of the tile belongs to the running slice (all but one tile in ~10^3 at C4): no slice test per
             // k-block, the validity bits from the ballot of stage (1), nothing but loads and matrix instructions in the loop
             constexpr int SG_UNR = NT == 1 ? 8 : 2;
@@ -368,6 +484,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     flush(cur, true);
     if (a.has_om) {
         double *dst = a.part_om + w_id * (size_t)(wOl * wOr);
+        if constexpr (NS > 0) {
+            edge_store(eO, dst, wOr, wOl, wOr);
+            return;
+        }
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
@@ -562,6 +682,10 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
         if (F.w > widest) widest = F.w;
     }
     const int NT = widest > 16 ? 2 : 1;
+    int wmax = 1;
+    for (int i = 0; i < 3; ++i) wmax = a.f[i].w > wmax ? a.f[i].w : wmax;
+    static const int edges_on = [] { const char *e = getenv("TTSK_SG_EDGES"); return e ? atoi(e) : 1; }();
+    const int NS = (NT == 2 && edges_on && wmax > 16 && wmax <= 24) ? (wmax <= 20 ? 1 : 2) : 0;   // strips beyond the first 16 columns
 #ifdef TTSK_LAB
     { const char *e = getenv("TTSK_SG_LAB"); a.lab = e ? atoi(e) : 0; }
 #endif
@@ -601,13 +725,17 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     a.part_j = (int *)(a.part_om + wtot * (size_t)cellsO);
     static PerInit attr;
     if (attr.first()) {
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     }
     const bool prof = prof_on();
     if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");
-    if (NT == 1) hipLaunchKernelGGL(sg_pass_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(sg_pass_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (NT == 1) hipLaunchKernelGGL((sg_pass_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else if (NS == 1) hipLaunchKernelGGL((sg_pass_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else if (NS == 2) hipLaunchKernelGGL((sg_pass_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((sg_pass_kernel<2, 0>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     TTSK_LAUNCH_CHECK();
     const int64_t rb = n < 4096 ? n : 4096;
     hipLaunchKernelGGL(sg_psi_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, a.part_psi, a.part_j, (int)wtot, wA, wB, n, dev_psi);
