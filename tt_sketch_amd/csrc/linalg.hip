@@ -165,8 +165,13 @@ __global__ __launch_bounds__(1024) void jacobi_pinv_kernel(const double *__restr
                                                            double *V, double rcond, double *P,
                                                            int *rank_out, double *svd_US,
                                                            double *svd_S, double *svd_Vt,
-                                                           const int *run_if_nonzero = nullptr)
+                                                           const int *run_if_nonzero = nullptr, int64_t om_stride = 0,
+                                                           int64_t p_stride = 0)
 {
+    // a batch of equally spaced matrices: workgroup b takes matrix b (grid 1, strides 0: the plain call)
+    omega += (int64_t)blockIdx.x * om_stride;
+    P += (int64_t)blockIdx.x * p_stride;
+    if (run_if_nonzero) run_if_nonzero += blockIdx.x;
     // queued behind the normal-equations attempt without the host having looked at its verdict (ttsk_pinv_end):
     // nothing to do if that attempt was accepted
     if (run_if_nonzero && *run_if_nonzero == 0) return;
@@ -1566,7 +1571,7 @@ int ttsk_pinv_end(const double *dev_omega, int64_t l, int64_t r, double rcond, d
     auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_omega, l, r, transposed, ws,
                        ws + mW * nW, rcond, dev_pinv, host_rank ? drank : (int *)nullptr, (double *)nullptr,
-                       (double *)nullptr, (double *)nullptr, predicate);
+                       (double *)nullptr, (double *)nullptr, predicate, (int64_t)0, (int64_t)0);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && host_rank) {
         e = hipMemcpyAsync(host_rank, drank, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -1630,9 +1635,20 @@ int ttsk_pinv_batch(int count, const double *const *dev_omegas, int64_t l, int64
     if (jm < 0) return TTSK_ERR_HIP;
     auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
     const double rcond = pinv_rcond(l, r, -1.0);
+    // equally spaced inputs and outputs, matrices that live in LDS (no shared global scratch): ONE launch, a workgroup per matrix
+    // (five launches of a kernel that leaves at once were 23 us of a 0.26 ms to_tt at C3)
+    bool spaced = jm == 2 && count >= 2;
+    const int64_t os = count >= 2 ? Om[1] - Om[0] : 0, ps = count >= 2 ? P[1] - P[0] : 0;
+    for (int b = 2; b < count && spaced; ++b) spaced = Om[b] - Om[b - 1] == os && P[b] - P[b - 1] == ps;
+    if (spaced && os >= 0 && ps > 0) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(1024), jl, st, Om[0], l, r, transposed, ws, ws + mW * nW, rcond, P[0], (int *)nullptr,
+                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (const int *)status, os, ps);
+        TTSK_LAUNCH_CHECK();
+        return TTSK_OK;
+    }
     for (int b = 0; b < count; ++b) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, Om[b], l, r, transposed, ws, ws + mW * nW, rcond, P[b], (int *)nullptr,
-                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (const int *)(status + b));
+                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (const int *)(status + b), (int64_t)0, (int64_t)0);
         TTSK_LAUNCH_CHECK();
     }
     return TTSK_OK;
@@ -1797,7 +1813,7 @@ int ttsk_svd_small(const double *dev_A, int64_t m, int64_t n, double *dev_US, do
     if (jm < 0) return TTSK_ERR_HIP;
     auto kern = jm == 2 ? jacobi_pinv_kernel<2> : (jm == 1 ? jacobi_pinv_kernel<1> : jacobi_pinv_kernel<0>);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), jl, st, dev_A, m, n, 0, ws, ws + m * n, 0.0,
-                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt, (const int *)nullptr);
+                       (double *)nullptr, (int *)nullptr, dev_US, dev_S, dev_Vt, (const int *)nullptr, (int64_t)0, (int64_t)0);
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }

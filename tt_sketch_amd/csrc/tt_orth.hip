@@ -470,6 +470,16 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
     }
     // "right" direction, pseudo-inverses batched, interior modes of one size: their products (and the refinement's) as
     // batched launches on `stream` as well -- 3 launches + the copies instead of 3 per pair
+    // A helper stream is forked the first time a pair actually lands on it and exactly the forked ones are joined at the end.
+    // The end pairs (never grouped) get theirs here, behind the pseudo-inverses and IN FRONT of the grouped launches: they run
+    // beside those instead of behind them (one C3 to_tt: ~30 us).
+    bool forked[TTSK_NUM_STREAMS] = {};
+    auto qof = [&](int k) { return (stream + 1 + k) % TTSK_NUM_STREAMS; };
+    if (batched && direction == 0 && d - 1 >= 3)
+        for (int k : {0, d - 2}) {
+            const int q = qof(k);
+            if (q != stream && !forked[q]) { CK(ttsk_stream_wait(q, stream)); forked[q] = true; }
+        }
     std::vector<char> grouped(d - 1, 0);
     if (batched && direction == 0 && d - 1 >= 3) {
         std::vector<int> G;
@@ -497,8 +507,15 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
             if (rc == 1) {
                 for (int b = 0; b < nb; ++b) grouped[G[b]] = 1;
                 if (refine) {
-                    for (int b = 0; b < nb; ++b)
-                        TTSK_HIP(hipMemcpyAsync(R[b], A[b], (size_t)m * r * 8, hipMemcpyDeviceToDevice, st));
+                    // R <- Psi: the interior cores of a packed sketch lie behind one another: one copy
+                    bool adjacent = true;
+                    for (int b = 1; b < nb; ++b) adjacent = adjacent && A[b] == A[b - 1] + (size_t)m * r;
+                    if (adjacent) {
+                        TTSK_HIP(hipMemcpyAsync(R[0], A[0], (size_t)nb * m * r * 8, hipMemcpyDeviceToDevice, st));
+                    } else {
+                        for (int b = 0; b < nb; ++b)
+                            TTSK_HIP(hipMemcpyAsync(R[b], A[b], (size_t)m * r * 8, hipMemcpyDeviceToDevice, st));
+                    }
                     const double *Cc[SK_MAXB];
                     for (int b = 0; b < nb; ++b) Cc[b] = C[b];
                     rc = skinny_try_batch(desc(m, r, l, -1.0, 1), nb, Cc, Om, R, stream, st);           // R = Psi - C Omega
@@ -513,13 +530,11 @@ int ttsk_tt_assemble(int d, const int64_t *n, const int64_t *lr, const int64_t *
             }
         }
     }
-    // A helper stream is forked the first time a pair actually lands on it (grouped pairs never touch theirs, so "k below
-    // the stream count" is not that moment: with d - 1 >= 10 an ungrouped pair k >= 9 could meet a stream whose earlier pair
-    // k - 8 had been grouped and that was therefore never forked) and exactly the forked ones are joined at the end.
-    bool forked[TTSK_NUM_STREAMS] = {};
+    // (grouped pairs never touch a helper stream, so "k below the stream count" is not the moment to fork: with d - 1 >= 10 an
+    // ungrouped pair could meet a stream whose earlier pair had been grouped and that was therefore never forked)
     for (int k = 0; k < d - 1; ++k) {
         if (grouped[k]) continue;
-        const int q = (stream + k) % TTSK_NUM_STREAMS;
+        const int q = qof(k);
         if (q != stream && !forked[q]) { CK(ttsk_stream_wait(q, stream)); forked[q] = true; }     // fork
         if (!batched) {
             CK(ttsk_pinv_begin(omega[k], lr[k], rr[k], -1.0, work[k], q));

@@ -359,11 +359,16 @@ def _assemble_one_call(Psi, Om, direction):
         want = (1 if mu == 0 else lr[mu - 1], n[mu], 1 if mu == d - 1 else rr[mu])
         if tuple(p.shape) != want:
             return None
+    # every output and the pseudo-inverses in ONE allocation (a dozen pool round trips cost the host more than the device idles
+    # for); pieces of equal shape are equally spaced
+    from .tt_fused import _carve
     if direction == "right":
-        cores = [DevArray.empty((1 if mu == 0 else lr[mu - 1], n[mu], lr[mu])) for mu in range(d - 1)] + [Psi[-1]]
+        shapes = [(1 if mu == 0 else lr[mu - 1], n[mu], lr[mu]) for mu in range(d - 1)]
     else:
-        cores = [Psi[0]] + [DevArray.empty((rr[mu - 1], n[mu], 1 if mu == d - 1 else rr[mu])) for mu in range(1, d)]
-    work = [DevArray.empty((rr[k], lr[k])) for k in range(d - 1)]
+        shapes = [(rr[mu - 1], n[mu], 1 if mu == d - 1 else rr[mu]) for mu in range(1, d)]
+    arrs = _carve(shapes + [(rr[k], lr[k]) for k in range(d - 1)])
+    cores = arrs[:d - 1] + [Psi[-1]] if direction == "right" else [Psi[0]] + arrs[:d - 1]
+    work = arrs[d - 1:]
     I64, P = ctypes.c_int64, ctypes.c_void_p
     nat.call("ttsk_tt_assemble", d, (I64 * d)(*n), (I64 * (d - 1))(*lr), (I64 * (d - 1))(*rr), (P * d)(*[p.ptr for p in Psi]),
              (P * (d - 1))(*[o.ptr for o in Om]), (P * d)(*[c.ptr for c in cores]), (P * (d - 1))(*[w.ptr for w in work]),
