@@ -1014,7 +1014,8 @@ def run_extras(args, job):
     for name, fn in (("c5", bench_c5), ("c4", bench_c4), ("c2", bench_c2), ("c2_gaussian", lambda a, j: bench_c2(a, j, gaussian=True))):
         t0 = time.perf_counter()
         # (c2: a sketch is 4 ms and its first calls grow the library's scratch arenas by 1.3 GB -- a few more of both)
-        sub.steps, sub.warmup = (10, 3) if name.startswith("c2") else (5, 2)
+        # (c5: half a millisecond per sketch, two in flight -- enough of them for the pipeline to fill)
+        sub.steps, sub.warmup = (10, 3) if name.startswith("c2") else (30, 4) if name == "c5" else (5, 2)
         try:
             extra[name] = compact(fn(sub, job))
             extra[name]["bench_wall_s"] = time.perf_counter() - t0
