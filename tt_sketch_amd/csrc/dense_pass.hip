@@ -403,12 +403,16 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     // half the columns of U and half the rows of Z -- the accumulators of all 64 b fit, Z needs no partial sums over blocks
     // of b, the matrix work stays proportional to the ranks, and the tile is read twice, the kinds of a (t range, q range) one
     // dispatch round apart on one XCD.  Otherwise (first mode a multiple of 32 only): blocks of 32 with wider accumulators.
-    const bool split = !(n0 & 63) && (r > 40 || ll > 20);
+    // just beyond 20 / 40 (r <= 44, ll <= 24): one more strip of either still fits one kind of workgroup (11 spilled registers, outside the step loop)
+    static const int one_kind_on = [] { const char *e = getenv("TTSK_DP_ONE_KIND"); return e ? atoi(e) : 1; }();
+    const bool one_kind = one_kind_on && !(n0 & 63) && (r > 40 || ll > 20) && r <= 44 && ll <= 24;
+    const bool split = !one_kind && !(n0 & 63) && (r > 40 || ll > 20);
     const int p_half = split ? (int)((r + 1) / 2 + 3) / 4 * 4 : 0, z_half = split ? (int)((ll + 1) / 2 + 3) / 4 * 4 : 0;
     const int ushape = split ? (p_half <= 24 ? 3 : 4) : r <= 40 ? 0 : r <= 48 ? 1 : 2;
     const int zshape = split ? (z_half <= 12 ? 2 : 3) : ll <= 20 ? 0 : 1;
-    const int TP = ushape == 0 ? 2 : ushape == 1 ? 3 : ushape == 2 ? 4 : ushape == 3 ? 1 : 2, SP = ushape == 0 || ushape == 3 ? 2 : 0;
-    const int NB = (split || (ushape == 0 && zshape == 0 && !(n0 & 63))) ? 64 : 32, nbb = (int)(n0 / NB);
+    const int TP = one_kind ? 2 : ushape == 0 ? 2 : ushape == 1 ? 3 : ushape == 2 ? 4 : ushape == 3 ? 1 : 2;
+    const int SP = one_kind ? 3 : ushape == 0 || ushape == 3 ? 2 : 0;
+    const int NB = (one_kind || split || (ushape == 0 && zshape == 0 && !(n0 & 63))) ? 64 : 32, nbb = (int)(n0 / NB);
     const int kinds = split ? 2 : 1;
     // q ranges: about 256 workgroups for one block of b, about 1024 over all blocks otherwise (several rounds over the CUs even
     // out the ranges); a multiple of 8, and not more than there are tiles
@@ -449,7 +453,8 @@ extern "C" int ttsk_dense_first_pass(const double *X, int64_t n0, int64_t Q, int
     DensePass a{X, Q * T, (int)Q, (int)T, C, (int)ll, P, (int)r, (int)pr, zout, slab, nt, (int)nqc, zblock, split ? 1 : 0, p_half, z_half, dbg};
     if (prof_on()) prof_open_named(st, PROF_SOLVE, 0.0, "dense_pass");
     int rc;
-    if (split) {
+    if (one_kind) rc = dense_pass_launch<8, 2, 3, 1, 2>(a, grid, st);
+    else if (split) {
         if (ushape == 3) rc = zshape == 2 ? dense_pass_launch<8, 1, 2, 0, 3>(a, grid, st) : dense_pass_launch<8, 1, 2, 1, 0>(a, grid, st);
         else rc = zshape == 2 ? dense_pass_launch<8, 2, 0, 0, 3>(a, grid, st) : dense_pass_launch<8, 2, 0, 1, 0>(a, grid, st);
     } else if (NB == 64) rc = dense_pass_launch<8, 2, 2, 1, 1>(a, grid, st);
