@@ -58,7 +58,7 @@ struct SgPass {
 #endif
 };
 
-constexpr int SG_T = 32;         // nonzeros per staged tile
+constexpr int SG_T = 32;         // nonzeros per staged tile (the stretches of the waves are multiples of it)
 
 // ndtri as a CALL in this kernel: inlined at its two sites it takes the pass kernel to ~230 VGPRs (two waves per SIMD,
 // or 49 spilled registers under a tighter cap); the call costs a few scalar instructions per ~100 of arithmetic.
@@ -70,9 +70,9 @@ __device__ __forceinline__ uint64_t sg_flat(const SgF &f, uint64_t fl, uint64_t 
     return (f.src & 2) ? base + (uint64_t)(int64_t)j * f.mul : base;
 }
 
-__host__ __device__ inline size_t sg_per_wave(int tcols, int tab, int qcols)
+__host__ __device__ inline size_t sg_per_wave(int tcols, int tab, int qcols, int T)
 {
-    return (size_t)SG_T * tcols + tab + 4 * SG_T + SG_T / 2 + ((size_t)SG_T * qcols + 3) / 4;
+    return (size_t)T * tcols + tab + 4 * T + T / 2 + ((size_t)T * qcols + 3) / 4;
 }
 
 // NT: 16-column matrix tiles per factor.  NT = 1 (every factor <= 16 columns: C4) is the round-3 kernel; NT = 2 takes
@@ -87,10 +87,14 @@ __device__ __forceinline__ double sg_mfma4(double a, double b, double c) { retur
 template <int NS> struct SgEdge { v4d t; double sb[NS], sa[NS], c[NS]; };
 template <int NS> struct SgOps { double t, s[NS], b1; };
 
-template <int NT, int NS>
+// T: nonzeros per staged tile.  32, or 16 where three wide factors would leave room for ONE workgroup per CU (a 32-nonzero tile of
+// 72 staged columns is 24 KB of LDS per wave): the sampling stage then deals 4 columns of a nonzero over the wave instead of 2.
+template <int NT, int NS, int T>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 {
     static_assert(NS == 0 || NT == 2, "edge strips belong to the wide instantiation");
+    static_assert(T == 32 || T == 16, "tile of 32 or 16 nonzeros");
+    constexpr int CP = 64 / T;                         // columns of one nonzero evaluated side by side in the sampling stage
     constexpr int NSA = NS ? NS : 1;
     extern __shared__ double sg_lds[];
     __shared__ uint64_t salt[3][16 * NT];
@@ -102,18 +106,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     }
     __syncthreads();                                   // the only workgroup barrier: waves run free from here
     const int tcols = a.tcols;
-    // per-wave LDS: tile[SG_T][tcols] (the sampled factors) | table blocks [SG_T][2 units] | byte offsets of the table rows [3][SG_T] | val[SG_T] | j[SG_T] (int) |
-    // queue (ushort, SG_T * qcols)
-    const size_t per_wave = sg_per_wave(tcols, a.tab, a.qcols);
+    // per-wave LDS: tile[T][tcols] (the sampled factors) | table blocks [T][2 units] | byte offsets of the table rows [3][T] | val[T] | j[T] (int) |
+    // queue (ushort, T * qcols)
+    const size_t per_wave = sg_per_wave(tcols, a.tab, a.qcols, T);
     double *tile = sg_lds + (size_t)wv * per_wave;
-    double *tabs = tile + SG_T * tcols;
+    double *tabs = tile + T * tcols;
     uint64_t *ro = (uint64_t *)(tabs + a.tab);
-    double *rv = (double *)(ro + 3 * SG_T);
-    int *rj = (int *)(rv + SG_T);
-    unsigned short *q = (unsigned short *)(rj + SG_T);
+    double *rv = (double *)(ro + 3 * T);
+    int *rj = (int *)(rv + T);
+    unsigned short *q = (unsigned short *)(rj + T);
 
     // (finite values everywhere a product may read: the rows of nonzeros beyond the stretch are multiplied by val = 0)
-    for (int i = lane; i < SG_T * tcols + a.tab; i += 64) tile[i] = 0.0;
+    for (int i = lane; i < T * tcols + a.tab; i += 64) tile[i] = 0.0;
     const size_t w_id = (size_t)blockIdx.x * 4 + wv;
     const size_t beg = w_id * a.chunk;
     const int wA = a.f[0].w, wB = a.f[1].w;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     if (lane == 0) { pj[0] = jfirst; pj[1] = jfirst; pj[2] = 0; }
 
     // the records of the NEXT tile travel while this one is worked on
-    const int t32 = lane & 31, half = lane >> 5;
+    const int t32 = lane & (T - 1), half = lane / T;      // (nonzero of the tile, which of its CP column slots)
     auto rec_load = [&](size_t t0, uint64_t &xfl, uint64_t &xfr, int &xj, double &xv) {
         const size_t pos = t0 + t32;
         const bool in = pos < end;
@@ -209,20 +213,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     int nx_j;
     double nx_v;
     rec_load(beg, nx_fl, nx_fr, nx_j, nx_v);
-    for (size_t t0 = beg; t0 < end; t0 += SG_T) {
+    for (size_t t0 = beg; t0 < end; t0 += T) {
         // ---- (1) the records of the tile
         const uint64_t my_fl = nx_fl, my_fr = nx_fr;
         const int my_j = nx_j;
         const bool valid = my_j >= 0;
-        if (lane < SG_T) {
+        if (lane < T) {
 #pragma unroll
             for (int f = 0; f < 3; ++f)                // where the nonzero's row of table factor f starts (a missing nonzero: row 0)
-                if (a.f[f].kind == 1) ro[f * SG_T + lane] = valid ? sg_flat(a.f[f], my_fl, my_fr, my_j) * (uint64_t)(8 * a.f[f].w) : 0;
+                if (a.f[f].kind == 1) ro[f * T + lane] = valid ? sg_flat(a.f[f], my_fl, my_fr, my_j) * (uint64_t)(8 * a.f[f].w) : 0;
             rv[lane] = nx_v;
             rj[lane] = my_j;
         }
         const bool tile_one_slice = __ballot(valid && my_j != cur) == 0ull;
-        rec_load(t0 + SG_T, nx_fl, nx_fr, nx_j, nx_v);
+        rec_load(t0 + T, nx_fl, nx_fr, nx_j, nx_v);
         __builtin_amdgcn_wave_barrier();
         // ---- (2a) the table factors: row flat[t] of the table into a block [t][2 units] by LDS-DMA, 16 bytes per lane (unit
         // i = 64 k + lane of the block in instruction k: nonzero i / units, unit i % units of its row), no registers held: the rows
@@ -239,11 +243,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #endif
             double *blk = tabs + a.off[f];
 #pragma unroll 1
-            for (int i0 = 0; i0 < SG_T * F.units; i0 += 64) {
+            for (int i0 = 0; i0 < T * F.units; i0 += 64) {
                 const int i = i0 + lane;
                 const int t = (i * F.rcp) >> 16, cu = i - t * F.units;
-                if (t < SG_T) {
-                    const char *src = (const char *)F.table + ro[f * SG_T + t] + 16 * cu;
+                if (t < T) {
+                    const char *src = (const char *)F.table + ro[f * T + t] + 16 * cu;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                      (__attribute__((address_space(3))) void *)(blk + 2 * i0), 16, 0, 0);
                 }
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
 #endif
             if (F.kind == 2) {
                 const uint64_t flat = sg_flat(F, my_fl, my_fr, my_j);
-                for (int ci = 0; 2 * ci < F.w; ++ci) {          // the same trip count in both halves: the ballots below are wave-wide
-                    const int c = 2 * ci + half;
+                for (int ci = 0; CP * ci < F.w; ++ci) {         // the same trip count in every part: the ballots below are wave-wide
+                    const int c = CP * ci + half;
                     const bool act = valid && c < F.w;
                     const uint64_t h = mix64(flat + salt[f][c & (16 * NT - 1)]);
                     const uint64_t bits = (h | 0x2000000000000000ULL) & 0x3FFFFFFFFFFFFFFFULL;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
                 // off - rank_min ..; the products read [off, off + w).  Signs by both halves, the swaps by one lane per nonzero.
                 const uint64_t flat = sg_flat(F, my_fl, my_fr, my_j);
                 double *row = tile + t32 * tcols + (a.off[f] - F.rank_min);
-                for (int c = half; c < F.full; c += 2) {
+                for (int c = half; c < F.full; c += CP) {
                     double s = 0.0;
                     if (c < F.nnz) {
                         const uint64_t h = mix64(flat + salt[f][c]);
@@ -382,13 +386,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             auto run = [&](auto with_om, auto cleft) {
                 if (tile_one_slice) {
 #pragma unroll 2
-                    for (int b = 0; b < SG_T / 4; ++b) {
+                    for (int b = 0; b < T / 4; ++b) {
                         const double v = rv[4 * b + kq];
                         kblock(b, v, v, with_om, cleft);
                     }
                 } else {
 #pragma unroll 1
-                    for (int b = 0; b < SG_T / 4; ++b) {
+                    for (int b = 0; b < T / 4; ++b) {
                         const int e = 4 * b + kq;
                         const int je = rj[e];
                         const bool ok = je >= 0;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             auto run = [&](auto with_om, auto all_tiles) {
                 constexpr bool every = NT == 1 || decltype(all_tiles)::value;
 #pragma unroll SG_UNR
-                for (int b = 0; b < SG_T / 4; ++b) {
+                for (int b = 0; b < T / 4; ++b) {
                     const int e = 4 * b + kq;
                     double av[NT], bv[NT], cv[NT];
                     operands(b, rv[e], av, bv, cv);
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
             else { if (full) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
         } else {
 #pragma unroll 1
-            for (int b = 0; b < SG_T / 4; ++b) {
+            for (int b = 0; b < T / 4; ++b) {
                 const int e = 4 * b + kq;
                 const int je = rj[e];
                 const bool ok = je >= 0;
@@ -676,8 +680,8 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
         } else if (F.kind == 1) {                      // a block of its own behind the tile
             F.units = (F.w + 1) / 2;
             F.rcp = 65536 / F.units + 1;              // i / units == (i * rcp) >> 16 for i < 1024, units <= 16
-            a.off[i] = a.tab;
-            a.tab += SG_T * 2 * F.units;
+            a.off[i] = a.tab;                         // in doubles per nonzero of the tile here; times the tile size below
+            a.tab += 2 * F.units;
         }
         if (F.w > widest) widest = F.w;
     }
@@ -700,9 +704,17 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         return (size_t)v;
     }();
-    const size_t per_wave = sg_per_wave(a.tcols, a.tab, a.qcols);
+    // tile of 32 nonzeros; of 16 where 32 would leave LDS for one wide workgroup per CU only
+    static const int t16_on = [] { const char *e = getenv("TTSK_SG_T16"); return e ? atoi(e) : 1; }();
+    const size_t fixed = 16 * NT * 24 + 64;
+    int T = SG_T;
+    if (NT == 2 && t16_on && (size_t)(156 * 1024) / (sg_per_wave(a.tcols, SG_T * a.tab, a.qcols, SG_T) * 32 + fixed) < 2) T = 16;
+    for (int i = 0; i < 3; ++i)
+        if (a.f[i].kind == 1) a.off[i] *= T;
+    a.tab *= T;
+    const size_t per_wave = sg_per_wave(a.tcols, a.tab, a.qcols, T);
     const size_t lds = per_wave * 4 * 8;
-    size_t wg_per_cu = (size_t)(156 * 1024) / (lds + 16 * NT * 24 + 64);
+    size_t wg_per_cu = (size_t)(156 * 1024) / (lds + fixed);
     if (wg_per_cu > (NT == 1 ? 3u : 2u)) wg_per_cu = NT == 1 ? 3 : 2;
     if (wg_per_cu < 1) {
         set_error("ttsk_sparse_gauss_pass: a staged tile of %d columns does not fit the LDS", a.tcols);
@@ -725,17 +737,27 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     a.part_j = (int *)(a.part_om + wtot * (size_t)cellsO);
     static PerInit attr;
     if (attr.first()) {
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<1, 0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     }
     const bool prof = prof_on();
     if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");
-    if (NT == 1) hipLaunchKernelGGL((sg_pass_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else if (NS == 1) hipLaunchKernelGGL((sg_pass_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else if (NS == 2) hipLaunchKernelGGL((sg_pass_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((sg_pass_kernel<2, 0>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)blocks), wg(256);
+    if (NT == 1) hipLaunchKernelGGL((sg_pass_kernel<1, 0, 32>), grid, wg, lds, st, a);
+    else if (T == 32) {
+        if (NS == 1) hipLaunchKernelGGL((sg_pass_kernel<2, 1, 32>), grid, wg, lds, st, a);
+        else if (NS == 2) hipLaunchKernelGGL((sg_pass_kernel<2, 2, 32>), grid, wg, lds, st, a);
+        else hipLaunchKernelGGL((sg_pass_kernel<2, 0, 32>), grid, wg, lds, st, a);
+    } else {
+        if (NS == 1) hipLaunchKernelGGL((sg_pass_kernel<2, 1, 16>), grid, wg, lds, st, a);
+        else if (NS == 2) hipLaunchKernelGGL((sg_pass_kernel<2, 2, 16>), grid, wg, lds, st, a);
+        else hipLaunchKernelGGL((sg_pass_kernel<2, 0, 16>), grid, wg, lds, st, a);
+    }
     TTSK_LAUNCH_CHECK();
     const int64_t rb = n < 4096 ? n : 4096;
     hipLaunchKernelGGL(sg_psi_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, a.part_psi, a.part_j, (int)wtot, wA, wB, n, dev_psi);
