@@ -17,6 +17,10 @@ if [ $PART = all ] || [ $PART = stats ]; then
   for c in c2 c2g c4 c5; do
     run prof_r04_$c --kernel-trace --stats -d $R/prof_r04_$c -o bench --output-format csv -- python3 $B --config $c --steps 10 --warmup 2 --no-cpu
   done
+  # C5 with ONE sketch in flight: the launch sequence of a single sketch (the default record has two in flight)
+  export TTSK_BENCH_C5_INFLIGHT=1
+  run prof_r04_c5one --kernel-trace -d $R/prof_r04_c5one -o bench --output-format csv -- python3 $B --config c5 --steps 10 --warmup 2 --no-cpu
+  unset TTSK_BENCH_C5_INFLIGHT
 fi
 if [ $PART = all ] || [ $PART = pmc1 ]; then
   # 2. counters of the headline (separate passes): traffic, SQ tables incl. the wait attribution
@@ -43,6 +47,7 @@ if [ $PART = all ] || [ $PART = stats ]; then
   python3 profiles/by_grid.py gpurun_out/prof_r04d/bench_kernel_trace.csv gpurun_out/r04_kernel_by_grid.csv > gpurun_out/r04_by_grid.txt 2>&1
   python3 profiles/by_grid.py gpurun_out/prof_r04s/bench_kernel_trace.csv gpurun_out/r04_kernel_by_grid_single_stream.csv > gpurun_out/r04_by_grid_single.txt 2>&1
   python3 profiles/scripts/timeline.py gpurun_out/prof_r04_c5/bench_kernel_trace.csv 12 > gpurun_out/r04_c5_timeline.txt 2>&1
+  python3 profiles/scripts/timeline.py gpurun_out/prof_r04_c5one/bench_kernel_trace.csv 12 > gpurun_out/r04_c5_timeline_single.txt 2>&1
   python3 profiles/scripts/timeline.py gpurun_out/prof_r04_c2g/bench_kernel_trace.csv 12 > gpurun_out/r04_c2g_timeline.txt 2>&1
   cp gpurun_out/prof_r04_full/bench_kernel_stats.csv gpurun_out/r04_bench_full_kernel_stats.csv
   cp gpurun_out/prof_r04d/bench_kernel_stats.csv gpurun_out/r04_bench_kernel_stats.csv
