@@ -269,6 +269,11 @@ int ttsk_sparse_mode_order(const int64_t *dev_idx, int64_t row_stride, size_t N,
 int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
                             const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
                             const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream);
+/* the same with 32-bit flat indices (20 instead of 28 bytes per record): TTSK_ERR_UNSUPPORTED when a prefix or suffix extent
+ * reaches 2^31 */
+int ttsk_sparse_mode_stream_u32(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                            const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                            const double *dev_val, uint32_t *dev_fl, uint32_t *dev_fr, int32_t *dev_j, double *dev_v, int stream);
 /* one DRM factor of a pass: kind 0 = ones (width 1), 1 = table[flat][w] (every possible prefix sampled once:
  * ttsk_sparse_normal_table / ttsk_sparse_sign_table; allocated with one spare row: rows are fetched in 16-byte units), 2 = normals sampled in the pass: ndtri(u(hash(flat + hash(rank_min + c)
  * + seed))), 3 = sparse-sign rows sampled in the pass (fast_lazy_gaussian.pyx:121-180; whole row <= 32 entries);
@@ -284,6 +289,9 @@ typedef struct {
  * zero-initialised).  Stream in ascending j (ttsk_sparse_mode_stream); dev_j == NULL: one slice.  Widths <= 32 (one
  * 16-column matrix tile per factor up to 16, 2 x 2 tiles per product beyond).  No atomics: the result is bit-reproducible. */
 int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
+                           int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                           double *dev_psi, double *dev_omega, int stream);
+int ttsk_sparse_gauss_pass_u32(const uint32_t *dev_fl, const uint32_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
                            int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
                            double *dev_psi, double *dev_omega, int stream);
 /* stable sort permutation of the nonzeros by one index row (values < n): perm[i] = id of the i-th

@@ -88,7 +88,10 @@ def _bind(lib):
         "ttsk_sparse_mode_order": [P, c_int64, S, POINTER(I), POINTER(c_uint64), I, I, c_int64, P, I],
         "ttsk_sparse_mode_stream": [P, c_int64, P, S, POINTER(I), POINTER(c_uint64), I, POINTER(I), POINTER(c_uint64), I, I,
                                     P, P, P, P, P, I],
+        "ttsk_sparse_mode_stream_u32": [P, c_int64, P, S, POINTER(I), POINTER(c_uint64), I, POINTER(I), POINTER(c_uint64), I, I,
+                                    P, P, P, P, P, I],
         "ttsk_sparse_gauss_pass": [P, P, P, P, S, c_int64, P, P, P, I, P, P, I],
+        "ttsk_sparse_gauss_pass_u32": [P, P, P, P, S, c_int64, P, P, P, I, P, P, I],
         "ttsk_sparse_sort_mode": [P, S, c_int64, P, I],
         "ttsk_pinv": [P, c_int64, c_int64, c_double, P, POINTER(I), I],
         "ttsk_pinv_begin": [P, c_int64, c_int64, c_double, P, I],
@@ -160,7 +163,7 @@ _STREAM_LAST = frozenset((
     "ttsk_memset", "ttsk_d2d", "ttsk_gemm", "ttsk_copy_strided", "ttsk_axpby", "ttsk_sum_slices",
     "ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_chain_step", "ttsk_chain_step_wide", "ttsk_sparse_normal_dev", "ttsk_sparse_sign_dev",
     "ttsk_fill_normal", "ttsk_fill_normal_many", "ttsk_sparse_ttdrm_step", "ttsk_sparse_densedrm_gather", "ttsk_sparse_psi",
-    "ttsk_sparse_sort_mode", "ttsk_sparse_normal_table", "ttsk_sparse_sign_table", "ttsk_sparse_mode_order", "ttsk_sparse_mode_stream", "ttsk_sparse_gauss_pass", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
+    "ttsk_sparse_sort_mode", "ttsk_sparse_normal_table", "ttsk_sparse_sign_table", "ttsk_sparse_mode_order", "ttsk_sparse_mode_stream", "ttsk_sparse_mode_stream_u32", "ttsk_sparse_gauss_pass", "ttsk_sparse_gauss_pass_u32", "ttsk_pinv", "ttsk_pinv_begin", "ttsk_pinv_end", "ttsk_triu", "ttsk_svd_small",
     "ttsk_qr_thin", "ttsk_orth_step", "ttsk_orth_step_pinv", "ttsk_pinv_batch_deferred", "ttsk_pinv_batch", "ttsk_dense_first_pass", "ttsk_tt_orth_sketch", "ttsk_tt_orth_sketch_batch", "ttsk_tt_assemble", "ttsk_comm_allreduce_sum", "ttsk_comm_reduce_sum", "ttsk_comm_allgather", "ttsk_comm_allreduce_max", "ttsk_graph_launch", "ttsk_timer_start"))
 _BLOCKING = frozenset(("ttsk_h2d", "ttsk_d2h"))          # return only after their stream has drained
 _TWO_STREAMS = frozenset(("ttsk_tt_sketch", "ttsk_tt_sketch_batch", "ttsk_tt_sketch_sum", "ttsk_tt_orth_sketch"))   # fork a helper on stream + 1, joined back

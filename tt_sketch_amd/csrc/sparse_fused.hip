@@ -39,7 +39,8 @@ struct SgF {
 };
 
 struct SgPass {
-    const uint64_t *fl, *fr;
+    const uint64_t *fl, *fr;   // flat prefix / suffix index of every record (w32: arrays of uint32 behind these pointers)
+    int w32;
     const int32_t *jj;
     const double *val;
     size_t N, chunk;     // nonzeros, nonzeros per wave (multiple of 32)
@@ -204,8 +205,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void sg_pass_kernel(SgPass a)
     auto rec_load = [&](size_t t0, uint64_t &xfl, uint64_t &xfr, int &xj, double &xv) {
         const size_t pos = t0 + t32;
         const bool in = pos < end;
-        xfl = (in && a.fl) ? a.fl[pos] : 0;
-        xfr = (in && a.fr) ? a.fr[pos] : 0;
+        if (a.w32) {
+            xfl = (in && a.fl) ? ((const uint32_t *)a.fl)[pos] : 0;
+            xfr = (in && a.fr) ? ((const uint32_t *)a.fr)[pos] : 0;
+        } else {
+            xfl = (in && a.fl) ? a.fl[pos] : 0;
+            xfr = (in && a.fr) ? a.fr[pos] : 0;
+        }
         xj = in ? (a.jj ? a.jj[pos] : 0) : -1;
         xv = in ? a.val[pos] : 0.0;
     };
@@ -546,14 +552,15 @@ __global__ __launch_bounds__(256) void sg_om_reduce_kernel(const double *__restr
 }
 
 // the resident stream of one mode: record pos = nonzero perm[pos]
+template <typename FLAT>
 __global__ void sg_stream_kernel(const int64_t *__restrict__ idx, IndexMap lm, IndexMap rm, int64_t mode_off,
-                                 const int64_t *__restrict__ perm, const double *__restrict__ val, size_t N, uint64_t *__restrict__ fl,
-                                 uint64_t *__restrict__ fr, int32_t *__restrict__ jj, double *__restrict__ vv)
+                                 const int64_t *__restrict__ perm, const double *__restrict__ val, size_t N, FLAT *__restrict__ fl,
+                                 FLAT *__restrict__ fr, int32_t *__restrict__ jj, double *__restrict__ vv)
 {
     for (size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pos < N; pos += (size_t)gridDim.x * blockDim.x) {
         const size_t e = perm ? (size_t)perm[pos] : pos;
-        fl[pos] = lm.m ? flat_index(idx, lm, e) : 0;
-        fr[pos] = rm.m ? flat_index(idx, rm, e) : 0;
+        fl[pos] = (FLAT)(lm.m ? flat_index(idx, lm, e) : 0);
+        fr[pos] = (FLAT)(rm.m ? flat_index(idx, rm, e) : 0);
         jj[pos] = (int32_t)idx[mode_off + (int64_t)e];
         vv[pos] = val[e];
     }
@@ -624,9 +631,9 @@ int ttsk_sparse_mode_order(const int64_t *dev_idx, int64_t row_stride, size_t N,
     return TTSK_OK;
 }
 
-int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
-                            const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
-                            const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream)
+static int sg_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                          const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                          const double *dev_val, void *dev_fl, void *dev_fr, int w32, int32_t *dev_j, double *dev_v, int stream)
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(dev_idx && dev_val && dev_fl && dev_fr && dev_j && dev_v, "ttsk_sparse_mode_stream: NULL argument");
@@ -638,15 +645,62 @@ int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const in
     if (N == 0) return TTSK_OK;
     size_t blocks = (N + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(sg_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dev_idx, lm, rm, (int64_t)mode_row * row_stride, dev_perm,
-                       dev_val, N, dev_fl, dev_fr, dev_j, dev_v);
+    if (w32) {
+        // 32-bit records only where every flat index fits (no wrap of the reference's 32-bit running product either)
+        double pl = 1.0, pr = 1.0;
+        for (int i = 0; i < l_m; ++i) pl *= (double)l_shape[i];
+        for (int i = 0; i < r_m; ++i) pr *= (double)r_shape[i];
+        if (!(pl < 2147483648.0) || !(pr < 2147483648.0)) {
+            set_error("ttsk_sparse_mode_stream_u32: %g prefixes / %g suffixes do not fit 32-bit records", pl, pr);
+            return TTSK_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(sg_stream_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, st, dev_idx, lm, rm, (int64_t)mode_row * row_stride,
+                           dev_perm, dev_val, N, (uint32_t *)dev_fl, (uint32_t *)dev_fr, dev_j, dev_v);
+    } else {
+        hipLaunchKernelGGL(sg_stream_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, st, dev_idx, lm, rm, (int64_t)mode_row * row_stride,
+                           dev_perm, dev_val, N, (uint64_t *)dev_fl, (uint64_t *)dev_fr, dev_j, dev_v);
+    }
     TTSK_LAUNCH_CHECK();
     return TTSK_OK;
 }
 
+int ttsk_sparse_mode_stream(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                            const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                            const double *dev_val, uint64_t *dev_fl, uint64_t *dev_fr, int32_t *dev_j, double *dev_v, int stream)
+{
+    return sg_mode_stream(dev_idx, row_stride, dev_perm, N, l_rows, l_shape, l_m, r_rows, r_shape, r_m, mode_row, dev_val, dev_fl, dev_fr, 0,
+                          dev_j, dev_v, stream);
+}
+
+int ttsk_sparse_mode_stream_u32(const int64_t *dev_idx, int64_t row_stride, const int64_t *dev_perm, size_t N, const int *l_rows,
+                                const uint64_t *l_shape, int l_m, const int *r_rows, const uint64_t *r_shape, int r_m, int mode_row,
+                                const double *dev_val, uint32_t *dev_fl, uint32_t *dev_fr, int32_t *dev_j, double *dev_v, int stream)
+{
+    return sg_mode_stream(dev_idx, row_stride, dev_perm, N, l_rows, l_shape, l_m, r_rows, r_shape, r_m, mode_row, dev_val, dev_fl, dev_fr, 1,
+                          dev_j, dev_v, stream);
+}
+
+static int sg_gauss_pass(const void *dev_fl, const void *dev_fr, int w32, const int32_t *dev_j, const double *dev_val, size_t N,
+                         int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                         double *dev_psi, double *dev_omega, int stream);
+
 int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
                            int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
                            double *dev_psi, double *dev_omega, int stream)
+{
+    return sg_gauss_pass(dev_fl, dev_fr, 0, dev_j, dev_val, N, n, A, B, C, c_left, dev_psi, dev_omega, stream);
+}
+
+int ttsk_sparse_gauss_pass_u32(const uint32_t *dev_fl, const uint32_t *dev_fr, const int32_t *dev_j, const double *dev_val, size_t N,
+                               int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                               double *dev_psi, double *dev_omega, int stream)
+{
+    return sg_gauss_pass(dev_fl, dev_fr, 1, dev_j, dev_val, N, n, A, B, C, c_left, dev_psi, dev_omega, stream);
+}
+
+static int sg_gauss_pass(const void *dev_fl, const void *dev_fr, int w32, const int32_t *dev_j, const double *dev_val, size_t N,
+                         int64_t n, const ttsk_sg_factor *A, const ttsk_sg_factor *B, const ttsk_sg_factor *C, int c_left,
+                         double *dev_psi, double *dev_omega, int stream)
 {
     TTSK_STREAM(st, stream);
     TTSK_ARG(dev_val && dev_psi && n >= 1, "ttsk_sparse_gauss_pass: NULL argument");
@@ -654,7 +708,7 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
     TTSK_ARG(!C || dev_omega, "ttsk_sparse_gauss_pass: an Omega factor needs an output");
     if (N == 0) return TTSK_OK;
     SgPass a{};
-    a.fl = dev_fl; a.fr = dev_fr; a.jj = dev_j; a.val = dev_val; a.N = N; a.n = n;
+    a.fl = (const uint64_t *)dev_fl; a.fr = (const uint64_t *)dev_fr; a.w32 = w32; a.jj = dev_j; a.val = dev_val; a.N = N; a.n = n;
     const ttsk_sg_factor *fs[3] = {A, B, C};
     int cols = 0, widest = 1;
     for (int i = 0; i < 3; ++i) {
@@ -746,7 +800,7 @@ int ttsk_sparse_gauss_pass(const uint64_t *dev_fl, const uint64_t *dev_fr, const
         TTSK_HIP(hipFuncSetAttribute((const void *)sg_pass_kernel<2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     }
     const bool prof = prof_on();
-    if (prof) prof_open_named(st, PROF_SPARSE, 28.0 * (double)N, "sg_pass_kernel");
+    if (prof) prof_open_named(st, PROF_SPARSE, (w32 ? 20.0 : 28.0) * (double)N, "sg_pass_kernel");
     const dim3 grid((unsigned)blocks), wg(256);
     if (NT == 1) hipLaunchKernelGGL((sg_pass_kernel<1, 0, 32>), grid, wg, lds, st, a);
     else if (T == 32) {

@@ -125,14 +125,19 @@ def _mode_stream(tensor: SparseTensor, mu: int):
         perm = DevArray.empty((N,), dtype=np.int64)
         nat.call("ttsk_sparse_mode_order", ctypes.c_void_p(idx.ptr), N, ctypes.c_size_t(N), ints(r_rows), _u64(r_shape or [1]),
                  len(r_rows), int(order[mu]), int(tensor.shape[mu]), ctypes.c_void_p(perm.ptr), 0)
-        fl, fr = DevArray.empty((N,), dtype=np.int64), DevArray.empty((N,), dtype=np.int64)
+        # 32-bit flat indices where every prefix / suffix extent stays below 2^31 (20 instead of 28 bytes per record and pass)
+        small = (int(np.prod(l_shape or [1], dtype=object)) < 2**31 and int(np.prod(r_shape or [1], dtype=object)) < 2**31
+                 and os.environ.get("TTSK_SPARSE_U32", "1") != "0")
+        words = (N + 1) // 2 if small else N
+        fl, fr = DevArray.empty((words,), dtype=np.int64), DevArray.empty((words,), dtype=np.int64)
         jj = DevArray.empty(((N + 1) // 2,), dtype=np.int64)          # int32 records
         vv = DevArray.empty((N,))
-        nat.call("ttsk_sparse_mode_stream", ctypes.c_void_p(idx.ptr), N, ctypes.c_void_p(perm.ptr), ctypes.c_size_t(N),
+        nat.call("ttsk_sparse_mode_stream_u32" if small else "ttsk_sparse_mode_stream", ctypes.c_void_p(idx.ptr), N,
+                 ctypes.c_void_p(perm.ptr), ctypes.c_size_t(N),
                  ints(l_rows), _u64(l_shape or [1]), len(l_rows), ints(r_rows), _u64(r_shape or [1]), len(r_rows), int(order[mu]),
                  ctypes.c_void_p(val.ptr), ctypes.c_void_p(fl.ptr), ctypes.c_void_p(fr.ptr), ctypes.c_void_p(jj.ptr),
                  ctypes.c_void_p(vv.ptr), 0)
-        cache[key] = (fl, fr, jj, vv)
+        cache[key] = (fl, fr, jj, vv, small)
     return cache[key]
 
 
@@ -189,7 +194,7 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
     Psi, Omega, keep = [], [None] * (d - 1), []
     sampled, table_rows = 0, 0
     for mu in range(d):
-        fl, fr, jj, vv = _mode_stream(tensor, mu)
+        fl, fr, jj, vv, small = _mode_stream(tensor, mu)
         A = B = C = None
         if mu > 0:
             A, t = L.factor(mu - 1, 0)
@@ -214,10 +219,11 @@ def try_sparse_gauss_sketch(tensor, left_drm, right_drm, method):
                 sampled += f.w
         P = ctypes.c_void_p
         ref = lambda f: None if f is None else ctypes.byref(f)
-        nat.call("ttsk_sparse_gauss_pass", P(fl.ptr), P(fr.ptr), P(jj.ptr), P(vv.ptr), ctypes.c_size_t(N), int(shape[mu]),
+        nat.call("ttsk_sparse_gauss_pass_u32" if small else "ttsk_sparse_gauss_pass", P(fl.ptr), P(fr.ptr), P(jj.ptr), P(vv.ptr),
+                 ctypes.c_size_t(N), int(shape[mu]),
                  ref(A), ref(B), ref(C), c_left, P(psi.ptr), None if om is None else P(om.ptr), 0)
         Psi.append(psi)
     last_plan.clear()
-    last_plan.update(sampled_columns_per_nonzero=sampled, passes=d, stream_bytes_per_nonzero_and_pass=28,
+    last_plan.update(sampled_columns_per_nonzero=sampled, passes=d, stream_bytes_per_nonzero_and_pass=20 if small else 28,
                      riders={int(k): v for k, v in rider.items()})
     return Psi, Omega
