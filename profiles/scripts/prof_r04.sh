@@ -32,7 +32,8 @@ if [ $PART = all ] || [ $PART = pmc1 ]; then
   unset TTSK_SINGLE_STREAM
 fi
 if [ $PART = all ] || [ $PART = pmc2 ]; then
-  # 3. the other configurations: traffic per sketch (steps + warm-up sketches per run: 5 + 2, + 1 first call at c4) and SQ tables of their kernels
+  # 3. the other configurations: traffic per sketch (steps + warm-up sketches per run: 5 + 2, + 1 first call at c4; c5: + 18 drained
+  # and 20 back-to-back public calls = 45) and SQ tables of their kernels
   for c in c2 c2g c4 c5; do
     run pmc_r04f_$c --kernel-trace --pmc FETCH_SIZE -d $R/pmc_r04f_$c -o p --output-format csv -- python3 $B --config $c --steps 5 --warmup 2 --no-cpu
     run pmc_r04w_$c --kernel-trace --pmc WRITE_SIZE -d $R/pmc_r04w_$c -o p --output-format csv -- python3 $B --config $c --steps 5 --warmup 2 --no-cpu
@@ -63,7 +64,7 @@ if [ $PART = all ] || [ $PART = pmc2 ]; then
   python3 profiles/collect_traffic.py gpurun_out/pmc_r04f_c2 gpurun_out/pmc_r04w_c2 gpurun_out/r04_traffic.json --total c2_sketch 7 >> gpurun_out/r04_traffic.txt 2>&1
   python3 profiles/collect_traffic.py gpurun_out/pmc_r04f_c2g gpurun_out/pmc_r04w_c2g gpurun_out/r04_traffic.json --total c2_gaussian_sketch 7 --only 'dense_left_pass|rows_longk|skinny_r|skinny_s|copy_strided|gemm_f64|small_gemm' >> gpurun_out/r04_traffic.txt 2>&1
   python3 profiles/collect_traffic.py gpurun_out/pmc_r04f_c4 gpurun_out/pmc_r04w_c4 gpurun_out/r04_traffic.json --total c4_sketch 11 --only 'sg_pass|sg_psi_reduce|sg_om_reduce|fillBuffer' >> gpurun_out/r04_traffic.txt 2>&1
-  python3 profiles/collect_traffic.py gpurun_out/pmc_r04f_c5 gpurun_out/pmc_r04w_c5 gpurun_out/r04_traffic.json --total c5_sketch 7 --only 'chain_sum|skinny_r_reduce|stream_small|sum_slices|small_gemm|gemm_f64' >> gpurun_out/r04_traffic.txt 2>&1
+  python3 profiles/collect_traffic.py gpurun_out/pmc_r04f_c5 gpurun_out/pmc_r04w_c5 gpurun_out/r04_traffic.json --total c5_sketch 45 --only 'chain_sum|skinny_r_reduce|stream_small|sum_slices|small_gemm|gemm_f64' >> gpurun_out/r04_traffic.txt 2>&1
   for c in c2g c4 c5; do
     python3 profiles/sq_counters.py gpurun_out/pmc_r04sq_$c/p_counter_collection.csv "bench.py --config $c --steps 3 --warmup 1 --no-cpu" > gpurun_out/r04_sq_counters_$c.txt 2>&1
     python3 profiles/sq_counters.py gpurun_out/pmc_r04sqb_$c/p_counter_collection.csv "bench.py --config $c --steps 3 --warmup 1 --no-cpu" >> gpurun_out/r04_sq_counters_$c.txt 2>&1
