@@ -364,3 +364,27 @@ def test_orthogonal_sketch_batch_verdict_per_tensor_and_fallbacks(tsa, monkeypat
     res, L, R = tsa.orthogonal_sketch_batch(mixed[:1] * 3, l, r, seed=5, return_drm=True)
     assert type(L).__name__ == "TensorTrainDRM" and len(res) == 3
     _close([np.asarray(a) for a in res[0].cores], [np.asarray(b) for b in res[2].cores])
+
+
+def test_batch_entries_beyond_one_slice_and_of_one_tensor(tsa):
+    """20 tensors = two slices of the batch entry (16 + 4); a list of one tensor goes through the single call; default DRMs of
+    hmt_sketch_batch are one DRM for all."""
+    shape, s_in, l, r = (24, 20, 22, 18), 9, 6, 11
+    d = len(shape)
+    rng = np.random.default_rng(21)
+    ld, rd = orc.random_tt_drm(shape, l, False, rng), orc.random_tt_drm(shape, r, True, rng)
+    left, right = _dev_drms(tsa, shape, (l,) * (d - 1), (r,) * (d - 1), ld, rd)
+    all_cores = [orc.random_tt(shape, s_in, rng) for _ in range(20)]
+    tts = [tsa.TensorTrain(c) for c in all_cores]
+    got = tsa.orthogonal_sketch_batch(tts, (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+    assert len(got) == 20
+    for k in (0, 15, 16, 19):
+        want, _ = orc.general_sketch("tt", all_cores[k], ld, rd, "orthogonal")
+        _close([np.asarray(c) for c in got[k].cores], want)
+    one = tsa.orthogonal_sketch_batch(tts[:1], (l,) * (d - 1), (r,) * (d - 1), left_drm=left, right_drm=right)
+    want, _ = orc.general_sketch("tt", all_cores[0], ld, rd, "orthogonal")
+    _close([np.asarray(c) for c in one[0].cores], want)
+    res, drm = tsa.hmt_sketch_batch(tts[:3], r, seed=4, return_drm=True)
+    assert type(drm).__name__ == "TensorTrainDRM" and drm.transpose and len(res) == 3
+    for t, g in zip(tts[:3], res):
+        assert g.error(t, relative=True) < 1e-9            # sketch rank 11 covers the TT rank 9: exact recovery
