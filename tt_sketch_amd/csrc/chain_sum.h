@@ -20,6 +20,7 @@
 // global_load_lds from all eight waves while phase A runs) + G image.  Two barriers per slice.
 // Partial results per (term, slice range) go to slabs; skinny_r_reduce sums them (fixed order, no atomics).
 #pragma once
+#include <cstddef>
 #include "chain_fused.h"
 
 namespace ttsk {
@@ -60,6 +61,16 @@ struct ChainSumS {
     int eunits;                   // 16-byte units of the E image (multiple of 64)
     int xcd_map;                  // 1: the term groups of a slice range share an XCD (E_k from one L2)
     int c_fast;                   // G loader: 1 = c is the contiguous index of X (right chain), 0 = j
+    // What the set-up would otherwise derive with divisions and 64-bit products: it runs once per workgroup, on a cold
+    // instruction cache, with nothing else resident on the CU -- its length in INSTRUCTIONS is what it costs (1640 of
+    // them took 13 k cycles of a 110 k-cycle launch).
+    int kbase, krem;              // slice range rr = [rr kbase + min(rr, krem), + kbase + (rr < krem))
+    int inv_ng;                   // (1 << 20) / ngroups + 1: i / ngroups == (i * inv_ng) >> 20 for i * ngroups < 2^20
+    int wpt, per, gu;             // G loader: waves per term (8 / tpw), elements per wave, loads per lane and slice
+    uint32_t w_c8, x_j8, x_c8;    // byte strides as 32-bit numbers (the host checks that every offset fits)
+    uint32_t t_b8, t_a8;          // T: bytes per term, bytes per row a (n t_ld 8)
+    uint32_t slab_t8, slab_r8;    // slab: bytes per term (nranges J A2 8) and per slice range (J A2 8)
+    uint32_t e_inv;               // ceil(2^32 / A2P): unit U of the E image is in section (U e_inv) >> 32
 #ifdef TTSK_LAB                    // timing experiments: only in a lab build (-DTTSK_LAB), never in the shipped code object
     long long *stamps;            // s_memtime of workgroup 0, [slice][wave][8]
     int diag;                     // (results wrong) 1 no E DMA, 2 no phase A, 4 no phase B, 8 no G loads, 16 no barriers, 32 no fragment reads in
@@ -97,6 +108,7 @@ struct CsPre {
     uint32_t kstep, tkstep, tastep;
     int gl_lane, gl_tile, tl_lane, el_lane, es_lane;
     int k_beg, k_end, tb;
+    double greg0[GMAX];          // the first slice's G elements, on their way when the set-up ends
 };
 
 template <int JS, int KB1, int NA, bool WT>
@@ -106,45 +118,76 @@ __device__ __forceinline__ void cs_prologue(const ChainSumS &a, const ChainSumRo
     constexpr int JP = 4 * JS, KP = 4 * KB1, GMAX = CsPre<JS, KB1, NA>::GMAX;
     const int x16 = lane & 15, kq = lane >> 4;
     const int RP = a.RP, A2P = a.A2P, KB2 = a.KB2;
-    P.k_beg = (int)((int64_t)rr * a.n / a.nranges);
-    P.k_end = (int)((int64_t)(rr + 1) * a.n / a.nranges);
-    // ---- W fragments of this wave's phase-A unit; zero beyond (K1, A) and for a-tiles the wave does not own (they give
-    // zero columns of T that are not stored)
+#ifdef TTSK_LAB
+#define CS_PSTAMP(i) do { if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[((4 * 8) + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CS_PSTAMP(i) do { } while (0)
+#endif
+    P.k_beg = rr * a.kbase + (rr < a.krem ? rr : a.krem);
+    P.k_end = P.k_beg + a.kbase + (rr < a.krem ? 1 : 0);
     const int tb = g * a.tpw + ro.term;             // the term whose T columns this wave computes
     const bool tv = tb < a.nb;
     P.tb = tb;
+    // ---- G loader: the 8 / tpw waves of a term share its K1 x J slice (zero beyond)
+    const int wpt = a.wpt;                           // waves per term: 8, 4 or 2
+    const int lt = wpt == 8 ? 0 : (wpt == 4 ? w >> 2 : w >> 1), part = w - lt * wpt;
+    const int gt = g * a.tpw + lt;
+    const int per = a.per;                           // ceil(KP JP / wpt)
+    const int gu = a.gu;                             // loads per lane and slice (<= GMAX)
+#pragma unroll
+    for (int u = 0; u < GMAX; ++u) {
+        const uint32_t e = (uint32_t)(part * per + u * 64 + lane);
+        const bool in = u < gu && u * 64 + lane < per && e < (uint32_t)(KP * JP);
+        uint32_t c, j;
+        if constexpr (KP == JP) {                    // one division by a constant, the roles picked afterwards
+            const uint32_t q = e / (uint32_t)JP, r = e - q * (uint32_t)JP;
+            c = a.c_fast ? r : q;
+            j = a.c_fast ? q : r;
+        } else {
+            c = a.c_fast ? e % (uint32_t)KP : e / (uint32_t)JP;
+            j = a.c_fast ? e / (uint32_t)KP : e % (uint32_t)JP;
+        }
+        uint32_t off = j * a.x_j8 + c * a.x_c8;
+        asm volatile("" : "+v"(off));                // (computed in front of the select: no branch around it)
+        P.goff[u] = (in && gt < a.nb && c < (uint32_t)a.K1 && j < (uint32_t)a.J) ? off : OOB_OFF;
+        P.glds[u] = in ? lt * (KP * JP) + (int)(c * JP + j) : -1;
+    }
+    P.rx = make_rsrc(uniform_ptr(Xterm), a.x_extent * 8);
+    P.kstep = (uint32_t)(a.x_k * 8);
+    // first slice's G: requested in front of the W fragments (160 load instructions per workgroup stand in the queue
+    // for 2-3 k cycles; the barrier below needs only G)
+    double greg[GMAX];
+#pragma unroll
+    for (int u = 0; u < GMAX; ++u) greg[u] = ld8(P.rx, P.goff[u], __builtin_amdgcn_readfirstlane((uint32_t)P.k_beg * P.kstep));
+    asm volatile("" ::: "memory");
+    CS_PSTAMP(0);
+    // ---- W fragments of this wave's phase-A unit; zero beyond (K1, A) and for a-tiles the wave does not own (they give
+    // zero columns of T that are not stored)
     {
         const double *Wp = uniform_ptr(Wterm);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, ((int64_t)(a.K1 - 1) * a.w_c + a.A) * 8);
+        // lane offset of (row kq, this lane's column) or out of range, the k-block as the scalar offset: two instructions per load
+        // (with the conditions inside the offset expression the compiler built a branch around every load)
+        uint32_t wrow = (uint32_t)kq * a.w_c8;
+        const uint32_t wstep = 4u * a.w_c8;
+        uint32_t rmask[KB1];
 #pragma unroll
-        for (int p = 0; p < NA; ++p)
+        for (int kb = 0; kb < KB1; ++kb) rmask[kb] = 4 * kb + kq < a.K1 ? 0u : OOB_OFF;
 #pragma unroll
-            for (int kb = 0; kb < KB1; ++kb) {
-                const int c = 4 * kb + kq, col = 16 * (ro.at0 + p) + x16;
-                P.Wf[p][kb] = ld8(rw, (tv && p < ro.na && c < a.K1 && col < a.A) ? (uint32_t)(((int64_t)c * a.w_c + col) * 8) : OOB_OFF, 0);
-            }
+        for (int p = 0; p < NA; ++p) {
+            const int col = 16 * (ro.at0 + p) + x16;
+            uint32_t w0 = (wrow + 8u * (uint32_t)col) | ((tv && p < ro.na && col < a.A) ? 0u : OOB_OFF);
+            asm volatile("" : "+v"(w0));
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) P.Wf[p][kb] = ld8(rw, w0 | rmask[kb], (uint32_t)kb * wstep);
+        }
     }
-    // ---- G loader: the 8 / tpw waves of a term share its K1 x J slice (zero beyond)
-    const int wpt = 8 / a.tpw;                       // waves per term
-    const int lt = w / wpt, part = w - lt * wpt;
-    const int gt = g * a.tpw + lt;
-    const int per = (KP * JP + wpt - 1) / wpt;
-    const int gu = (per + 63) >> 6;                  // loads per lane and slice (<= GMAX)
-#pragma unroll
-    for (int u = 0; u < GMAX; ++u) {
-        const int e = part * per + u * 64 + lane;
-        const bool in = u < gu && u * 64 + lane < per && e < KP * JP;
-        const int c = a.c_fast ? e % KP : e / JP, j = a.c_fast ? e / KP : e % JP;
-        P.goff[u] = (in && gt < a.nb && c < a.K1 && j < a.J) ? (uint32_t)(((int64_t)j * a.x_j + (int64_t)c * a.x_c) * 8) : OOB_OFF;
-        P.glds[u] = in ? lt * (KP * JP) + c * JP + j : -1;
-    }
-    P.rx = make_rsrc(uniform_ptr(Xterm), a.x_extent * 8);
-    P.kstep = __builtin_amdgcn_readfirstlane((uint32_t)(a.x_k * 8));
+    CS_PSTAMP(1);
     // ---- E loader: unit U of the image = columns (2 (u >> 1), + 1) of row 2 sec + (u & 1), sec = U / A2P, u = U % A2P;
     // wave w issues instructions w, w + 8, ... (1 KB each); the per-lane source offsets are the same for every slice.
     // Rows beyond A repeat row A - 1 (they meet exact zeros of T).
     {
-        const uint32_t inv = (uint32_t)(((1ull << 32) + (uint32_t)A2P - 1) / (uint32_t)A2P);
+        const uint32_t inv = a.e_inv;                // ceil(2^32 / A2P)
         const int rowstride = a.n * a.A2;
 #pragma unroll
         for (int i = 0; i < CS_DMAMAX; ++i) {
@@ -158,6 +201,7 @@ __device__ __forceinline__ void cs_prologue(const ChainSumS &a, const ChainSumRo
             P.esrc[i] = (row * rowstride + col) * 8;   // bytes (< 2^32: checked by the host)
         }
     }
+    CS_PSTAMP(2);
     // lane offsets of the fragment reads
     P.gl_lane = ro.term * (KP * JP) + kq * JP + (x16 & 3);                   // + (4 kb) JP + 4 qs
     P.gl_tile = ro.term * (KP * JP) + kq * JP + x16;                         // G fragment of a 16-row tile: + (4 kb) JP + 16 q
@@ -173,23 +217,25 @@ __device__ __forceinline__ void cs_prologue(const ChainSumS &a, const ChainSumRo
     for (int p = 0; p < NA; ++p) {
         const int ai = 16 * (ro.at0 + p) + 4 * beta + kq;
         P.tw[p] = (p < ro.na && ai < 4 * KB2) ? (ai >> 1) * 2 * RP + 2 * (ro.term * JP + j4) + (ai & 1) : -1;
-        P.tg[p] = (WT && tv && p < ro.na && ai < a.A) ? (uint32_t)(((int64_t)tb * a.t_b + (int64_t)ai * a.n * a.t_ld + j4) * 8) : OOB_OFF;
+        if constexpr (WT) {
+            uint32_t o = (uint32_t)tb * a.t_b8 + (uint32_t)ai * a.t_a8 + 8u * (uint32_t)j4;
+            asm volatile("" : "+v"(o));
+            P.tg[p] = (tv && p < ro.na && ai < a.A) ? o : OOB_OFF;
+        } else P.tg[p] = OOB_OFF;
         const int at = 16 * (ro.at0 + p) + kq;
         P.twt[p] = p < ro.na ? (at >> 1) * 2 * RP + 2 * (ro.term * JP + x16) + (at & 1) : -1;
-        P.tgt[p] = (WT && tv && p < ro.na) ? (uint32_t)(((int64_t)tb * a.t_b + (int64_t)at * a.n * a.t_ld + x16) * 8) : OOB_OFF;
+        if constexpr (WT) {
+            uint32_t o = (uint32_t)tb * a.t_b8 + (uint32_t)at * a.t_a8 + 8u * (uint32_t)x16;
+            asm volatile("" : "+v"(o));
+            P.tgt[p] = (tv && p < ro.na) ? o : OOB_OFF;
+        } else P.tgt[p] = OOB_OFF;
     }
-    P.tkstep = __builtin_amdgcn_readfirstlane((uint32_t)(a.t_ld * 8));
-    P.tastep = (uint32_t)(4 * (int64_t)a.n * a.t_ld * 8);      // four rows a further in T
-    // first slice's G
-    double *GL = lds + a.gbase;
-    double greg[GMAX];
+    P.tkstep = (uint32_t)(a.t_ld * 8);
+    P.tastep = 4u * a.t_a8;                                    // four rows a further in T
+    CS_PSTAMP(3);
 #pragma unroll
-    for (int u = 0; u < GMAX; ++u) greg[u] = ld8(P.rx, P.goff[u], __builtin_amdgcn_readfirstlane((uint32_t)P.k_beg * P.kstep));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < GMAX; ++u)
-        if (P.glds[u] >= 0) GL[P.glds[u]] = greg[u];
-    __syncthreads();
+    for (int u = 0; u < GMAX; ++u) P.greg0[u] = greg[u];
+#undef CS_PSTAMP
 }
 
 // the wave's share of the workgroup: the slice loop (accumulators live across slices) and the partial results.
@@ -203,6 +249,9 @@ __device__ __forceinline__ void cs_wave(const ChainSumS &a, const ChainSumRole r
     constexpr int GMAX = CsPre<JS, KB1, NA>::GMAX;
     constexpr int NST = WT ? NA * (4 * (JS / 4) + JS % 4) : 0;   // T stores per slice (masked ones are issued out of range: static count)
     constexpr bool HS = SR > 0;
+#ifdef TTSK_LAB
+    if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[((5 * 8) + w) * 8 + 0] = __builtin_amdgcn_s_memtime();      // body entered
+#endif
     double *TL = lds, *EL = lds + a.ebase, *GL = lds + a.gbase;
     const int x16 = lane & 15, kq = lane >> 4;
     const int k_beg = P.k_beg, k_end = P.k_end;
@@ -250,6 +299,24 @@ __device__ __forceinline__ void cs_wave(const ChainSumS &a, const ChainSumRole r
         for (int r = 0; r < SR; ++r)
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc2s[r][s] = 0.0;
+    }
+
+    // The first slice's G into its image -- HERE, behind the switch over the bodies and this body's own set-up: the cold
+    // instruction fetches of both (2-3 k cycles) run while the loads are on their way instead of behind the barrier.
+    {
+#ifdef TTSK_LAB
+        if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[((4 * 8) + w) * 8 + 4] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u)
+            if (P.glds[u] >= 0) GL[P.glds[u]] = P.greg0[u];
+#ifdef TTSK_LAB
+        if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[((4 * 8) + w) * 8 + 5] = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+#ifdef TTSK_LAB
+        if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[((4 * 8) + w) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
     }
 
 #ifdef TTSK_LAB
@@ -449,23 +516,36 @@ __device__ __forceinline__ void cs_wave(const ChainSumS &a, const ChainSumRole r
 #undef CS_STAMP
 
     // ---- partial results: slab[term][range][j][a']
-    auto put = [&](int row, int col, double v) {
+    // (byte offsets as 32-bit numbers into one buffer descriptor, the row part once per row: this code runs once, cold,
+    // at the very end of the workgroup -- 24 stores with their own 64-bit index products took 6-7 k cycles)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.slab, (int64_t)a.nb * a.slab_t8);
+    const uint32_t slab0 = (uint32_t)rr * a.slab_r8;
+    auto rowoff = [&](int row) -> uint32_t {         // byte offset of slab[term of the row][rr][j][0], OOB_OFF = no such row
         const int lt2 = row / JP, j = row - lt2 * JP, t2 = g * a.tpw + lt2;
-        if (lt2 < a.tpw && t2 < a.nb && j < a.J && col < a.A2)
-            a.slab[(((int64_t)t2 * a.nranges + rr) * a.J + j) * a.A2 + col] = v;
+        return (lt2 < a.tpw && t2 < a.nb && j < a.J) ? slab0 + (uint32_t)t2 * a.slab_t8 + (uint32_t)(j * a.A2) * 8u : OOB_OFF;
     };
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t ro8 = rowoff(16 * (ro.rt0 + r) + 4 * t + kq);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) put(16 * (ro.rt0 + r) + 4 * t + kq, 16 * (ro.ct0 + c) + x16, acc2[r][c][t]);
+            for (int c = 0; c < CT; ++c) {
+                const int col = 16 * (ro.ct0 + c) + x16;
+                st8(rs, (ro8 != OOB_OFF && col < a.A2) ? ro8 + 8u * (uint32_t)col : OOB_OFF, acc2[r][c][t]);
+            }
+        }
     if constexpr (HS) {
         // 4x4x4 result: lane (i = kq, beta, j4) holds row 4 beta + i, column j4 of the strip
 #pragma unroll
-        for (int r = 0; r < SR; ++r)
+        for (int r = 0; r < SR; ++r) {
+            const uint32_t ro8 = rowoff(16 * r + 4 * beta + kq);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) put(16 * r + 4 * beta + kq, 16 * a.NNF + 4 * s + j4, acc2s[r][s]);
+            for (int s = 0; s < NS; ++s) {
+                const int col = 16 * a.NNF + 4 * s + j4;
+                st8(rs, (ro8 != OOB_OFF && col < a.A2) ? ro8 + 8u * (uint32_t)col : OOB_OFF, acc2s[r][s]);
+            }
+        }
     }
 }
 
@@ -481,31 +561,38 @@ __global__ __launch_bounds__(512, 2) void chain_sum_kernel(ChainSum a)
     extern __shared__ double cs_lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef TTSK_LAB
+    if (a.s.stamps && blockIdx.x == 0 && lane == 0) a.s.stamps[w * 8 + 6] = __builtin_amdgcn_s_memtime();      // kernel entry
+#endif
     int g, rr;
     if (a.s.xcd_map) {
         // blocks b and b + 8 share an XCD: all term groups of a slice range on the same one (they read the same E_k)
         const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        g = idx % a.s.ngroups;
-        rr = x + 8 * (idx / a.s.ngroups);
+        const int q = (int)(((uint32_t)idx * (uint32_t)a.s.inv_ng) >> 20);
+        g = idx - q * a.s.ngroups;
+        rr = x + 8 * q;
     } else {
-        g = blockIdx.x % a.s.ngroups;
-        rr = blockIdx.x / a.s.ngroups;
+        rr = (int)(((uint32_t)blockIdx.x * (uint32_t)a.s.inv_ng) >> 20);
+        g = (int)blockIdx.x - rr * a.s.ngroups;
     }
-    // (compare-and-select chains over the tables: indexed dynamically, the whole argument block is copied to scratch)
-    ChainSumRole ro = a.role[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-        if (w == i) ro = a.role[i];
+    // The wave's role and pointers, read from the kernel-argument segment at a computed (uniform) offset: one scalar load
+    // each.  (a.role[w] / a.W[tb] with a dynamic index make the compiler copy the whole argument block to scratch;
+    // compare-and-select chains over the tables were 270 scalar instructions and 128 SGPRs, spilled.)
+    typedef const __attribute__((address_space(4))) char *karg_t;
+    typedef const __attribute__((address_space(4))) unsigned long long *karg64_t;
+    const karg_t kp = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned long long rbits = *(karg64_t)(kp + offsetof(ChainSum, role) + 8 * w);
+    ChainSumRole ro;
+    ro.term = (unsigned char)(rbits & 0xff); ro.at0 = (unsigned char)((rbits >> 8) & 0xff); ro.na = (unsigned char)((rbits >> 16) & 0xff);
+    ro.body = (unsigned char)((rbits >> 24) & 0xff); ro.rt0 = (unsigned char)((rbits >> 32) & 0xff); ro.ct0 = (unsigned char)((rbits >> 40) & 0xff);
+    ro.pad0 = ro.pad1 = 0;
     // the term whose T columns this wave computes, and the term whose slice of X it brings in
-    const int tb = g * a.s.tpw + ro.term, gt = g * a.s.tpw + w / (8 / a.s.tpw);
-    const double *Wterm = a.W[0], *Xterm = a.X[0];
-#pragma unroll
-    for (int i = 1; i < SK_MAXB; ++i) {
-        if (tb == i) Wterm = a.W[i];
-        if (gt == i) Xterm = a.X[i];
-    }
+    const int wpt = a.s.wpt;
+    const int tb = g * a.s.tpw + ro.term, gt = g * a.s.tpw + (wpt == 8 ? 0 : (wpt == 4 ? w >> 2 : w >> 1));
+    const double *Wterm = (const double *)*(karg64_t)(kp + offsetof(ChainSum, W) + 8 * (tb < a.s.nb ? tb : 0));
+    const double *Xterm = (const double *)*(karg64_t)(kp + offsetof(ChainSum, X) + 8 * (gt < a.s.nb ? gt : 0));
 #ifdef TTSK_LAB
-    if (a.s.stamps && blockIdx.x == 0 && lane == 0) a.s.stamps[w * 8 + 6] = __builtin_amdgcn_s_memtime();      // kernel entry
+    if (a.s.stamps && blockIdx.x == 0 && lane == 0) a.s.stamps[(4 * 8 + w) * 8 + 6] = __builtin_amdgcn_s_memtime();      // role and pointers picked
 #endif
     CsPre<JS, KB1, NA> pre;
     cs_prologue<JS, KB1, NA, WT>(a.s, ro, Wterm, Xterm, cs_lds, g, rr, w, lane, pre);

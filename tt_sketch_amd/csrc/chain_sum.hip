@@ -227,10 +227,31 @@ int chain_sum_try(const ChainSumArgs &cc, int stream, hipStream_t st, bool force
     if (nr > c.n) nr = c.n;
     a.nranges = nr;
     a.xcd_map = (nr % 8 == 0) ? 1 : 0;
+    a.kbase = c.n / nr; a.krem = c.n % nr;
+    a.inv_ng = (1 << 20) / a.ngroups + 1;
+    if ((int64_t)a.ngroups * nr * a.ngroups >= (1 << 20)) return 0;
+    a.wpt = 8 / tpw;
+    a.e_inv = (uint32_t)(((1ull << 32) + (uint32_t)a.A2P - 1) / (uint32_t)a.A2P);
+    a.per = (KP * JP + a.wpt - 1) / a.wpt;
+    a.gu = (a.per + 63) / 64;
     // 32-bit byte offsets
-    if ((c.x_extent + c.x_k) * 8 >= (1ll << 32) - 64) return 0;
-    if ((int64_t)c.A * c.n * c.A2 * 8 >= (1ll << 32) - 64) return 0;
-    if (a.T && a.t_extent * 8 >= (1ll << 32) - 64) return 0;
+    const int64_t lim32 = (1ll << 32) - 64;
+    if ((c.x_extent + c.x_k) * 8 >= lim32) return 0;
+    if ((int64_t)c.A * c.n * c.A2 * 8 >= lim32) return 0;
+    if (a.T && a.t_extent * 8 >= lim32) return 0;
+    if (((int64_t)(c.K1 - 1) * c.w_c + c.A) * 8 >= lim32) return 0;
+    if ((c.J > 1 && c.x_j * 8 >= lim32) || (c.K1 > 1 && c.x_c * 8 >= lim32)) return 0;
+    a.w_c8 = (uint32_t)(c.w_c * 8);
+    a.x_j8 = c.J > 1 ? (uint32_t)(c.x_j * 8) : 0u;
+    a.x_c8 = c.K1 > 1 ? (uint32_t)(c.x_c * 8) : 0u;
+    if (a.T) {
+        if ((c.nb > 1 && cc.t_b * 8 >= lim32) || (c.A > 1 && (int64_t)c.n * cc.t_ld * 8 >= lim32)) return 0;
+        a.t_b8 = c.nb > 1 ? (uint32_t)(cc.t_b * 8) : 0u;
+        a.t_a8 = c.A > 1 ? (uint32_t)((int64_t)c.n * cc.t_ld * 8) : 0u;
+    }
+    if ((int64_t)c.nb * nr * c.J * c.A2 * 8 >= lim32) return 0;
+    a.slab_r8 = (uint32_t)((int64_t)c.J * c.A2 * 8);
+    a.slab_t8 = (uint32_t)((int64_t)nr * c.J * c.A2 * 8);
     for (int b = 0; b < c.nb; ++b) {
         if ((uintptr_t)c.X[b] & 7) return 0;
         ka.W[b] = c.W[b];
@@ -265,6 +286,11 @@ int chain_sum_try(const ChainSumArgs &cc, int stream, hipStream_t st, bool force
         for (int w = 0; w < 8; ++w)
             fprintf(stderr, "[cs stamps] wave %d: kernel entry -> first slice %lld cycles, last barrier -> behind the stores %lld cycles\n", w,
                     h[w * 8 + 0] - h[w * 8 + 6], h[w * 8 + 7] - h[(3 * 8 + w) * 8 + 5]);
+        for (int w = 0; w < 8; ++w) {
+            const long long *r = h + (4 * 8 + w) * 8, e = h[w * 8 + 6];
+            fprintf(stderr, "[cs stamps] prologue wave %d: picked %lld | G issued %lld | W issued %lld | E offsets %lld | lane offsets %lld | body entered %lld | G store begins %lld | G stored %lld | barrier passed %lld | first slice %lld\n", w,
+                    r[6] - e, r[0] - e, r[1] - e, r[2] - e, r[3] - e, h[(5 * 8 + w) * 8] - e, r[4] - e, r[5] - e, r[7] - e, h[w * 8 + 0] - e);
+        }
         fprintf(stderr, "[cs stamps] workgroup 0, cycles since its first stamp; slice, wave (body): start | endA | dma landed | afterB1 | endB | afterB2\n");
         for (int sl = 0; sl < 4; ++sl)
             for (int w = 0; w < 8; ++w) {
