@@ -221,7 +221,24 @@ int chain_sum_try(const ChainSumArgs &cc, int stream, hipStream_t st, bool force
     }
     a.ngroups = (c.nb + tpw - 1) / tpw;
     const int cus = cs_num_cu();
+    // Slice ranges per term group = workgroups per group.  A workgroup costs ~20 k cycles before and after its slices
+    // (set-up on a cold instruction cache, the switch, the partial results) during which its CU does nothing else -- 157 KB
+    // of LDS and 2 x 256 registers per SIMD leave no room for a second one -- so the grid is NOT one workgroup per CU at
+    // any price: (i) a workgroup gets at least ~32 k cycles of matrix-pipe time (one and a half times its fixed cost), (ii) a quarter of
+    // the CUs is left to the kernel of the other chain, which the sketch drivers always have in flight beside this one.
+    // (C5: 24 ranges of 5-6 slices for the right step and 16 of 8 for the left one instead of 32 of 4 each: 0.41 -> 0.39 ms
+    // per sketch with two in flight, a single call unchanged.)  TTSK_CS_NR / TTSK_CS_NR_LEFT (lab): the count itself.
+    static const int nr_env = [] { const char *e = getenv("TTSK_CS_NR"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    static const int nr_left_env = [] { const char *e = getenv("TTSK_CS_NR_LEFT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
     int nr = cus / a.ngroups;
+    {
+        const int NRT = (tpw * JP + 15) / 16;
+        const double slice_cyc = 64.0 * (2.0 * na_run * (JS / 4 + 0.25 * (JS % 4)) * KB1 + NRT * (a.NNF + 0.25 * a.NS) * a.KB2 / 4.0);
+        const int min_slices = (int)(32000.0 / slice_cyc) + 1;
+        nr = std::min(std::max(1, 3 * cus / 4 / a.ngroups), std::max(1, c.n / min_slices));
+    }
+    if (a.T && nr_left_env) nr = nr_left_env;
+    else if (!a.T && nr_env) nr = nr_env;
     if (nr >= 8) nr = nr / 8 * 8;
     if (nr < 1) nr = 1;
     if (nr > c.n) nr = c.n;

@@ -102,13 +102,24 @@ __global__ void axpby_kernel(double *y, const double *x, double a, double b, siz
 }
 
 // dst[i] (+)= sum_b src[b * stride + i]: the sketches of a batch summed into one (TensorSum)
+// (the slices are requested eight at a time and added in order: one load after the other, each waiting for the sum,
+// was 15 us for 32 slices of 6400 numbers -- a handful of workgroups, nothing to hide a round trip behind)
 __global__ __launch_bounds__(256) void sum_slices_kernel(double2 *dst, const double2 *src, int nb, size_t stride2,
                                                          size_t n2, int accumulate)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
         double2 acc = accumulate ? dst[i] : make_double2(0.0, 0.0);
-        for (int b = 0; b < nb; ++b) {
-            const double2 v = src[(size_t)b * stride2 + i];
+        const double2 *p = src + i;
+        int b = 0;
+        for (; b + 8 <= nb; b += 8, p += 8 * stride2) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)u * stride2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; }
+        }
+        for (; b < nb; ++b, p += stride2) {
+            const double2 v = *p;
             acc.x += v.x;
             acc.y += v.y;
         }
@@ -122,7 +133,16 @@ __global__ __launch_bounds__(256) void sum_slices_scalar_kernel(double *dst, con
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         double acc = accumulate ? dst[i] : 0.0;
-        for (int b = 0; b < nb; ++b) acc += src[(size_t)b * stride + i];
+        const double *p = src + i;
+        int b = 0;
+        for (; b + 8 <= nb; b += 8, p += 8 * stride) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < nb; ++b, p += stride) acc += *p;
         dst[i] = acc;
     }
 }
